@@ -1,0 +1,268 @@
+"""The CPU oracle against golden vectors captured from the reference (not gpu).
+
+Every expected value here was produced by the reference's own code
+(tools/make_golden.py, imported from /root/reference in the build container).  The oracle
+runs the same PyTorch CPU kernels, so agreement is expected to a few ulp; tolerances are
+stated per check.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+# ---- a1 ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["64", "5x7"])
+def test_rays(golden, tag):
+    g = golden(f"rays_{tag}")
+    H, W = int(g["H"]), int(g["W"])
+    batch, o, d, shape = O.ray_batch_from_camera(H, W, g["K"], T(g["c2w"]), 2.0, 6.0)
+    assert tuple(shape) == (H, W, 3)
+    close(batch, g["ray_batch"], rtol=0, atol=0)  # same ops on the same machine: bit exact
+    ro, rd = O.camera_rays(H, W, g["K"], T(g["c2w"]))
+    n = g["rays_o"].shape[0]
+    close(ro[:n], g["rays_o"], 0, 0)
+    close(rd[:n], g["rays_d"], 0, 0)
+
+
+def test_render_poses(golden):
+    g = golden("poses")["render_poses"]
+    mine = torch.stack([O.pose_spherical(a, -30.0, 4.0) for a in np.linspace(-180, 180, 41)[:-1]])
+    close(mine, g, 0, 1e-7)
+
+
+# ---- a2 ---------------------------------------------------------------------------------
+def test_sphere_golden(golden):
+    g = golden("sphere")
+    t, p = O.sphere_intersections(T(g["known_o"]), T(g["known_d"]), torch.tensor([1.0]))
+    close(t, g["known_t"], 0, 0)
+    close(p, g["known_p"], 0, 0)
+    t, p = O.sphere_intersections(T(g["o"]), T(g["d"]), torch.tensor([2.0]))
+    assert np.isnan(g["t"]).any() and not np.isnan(g["t"]).all()
+    close(t, g["t"], 0, 0)
+    close(p, g["p"], 0, 0)
+    close(O.solve_quadratic(T(g["qa"]), T(g["qb"]), T(g["qc"])), g["qs"], 0, 0)
+
+
+def test_quadratic_known_answers():
+    """Known answers of the reference's tests (nerf_sampling/tests/tests.py:197-233)."""
+    nan = float("nan")
+    close(O.solve_quadratic(torch.tensor([1.0]), torch.tensor([2.0]), torch.tensor([1.0])),
+          np.array([[-1.0], [-1.0]]))
+    a = torch.tensor([[1.0, 4, 5], [1, 4, 5]]); b = torch.tensor([[1.0, 4, 6], [1, 4, 6]])
+    c = torch.ones(2, 3)
+    close(O.solve_quadratic(a, b, c),
+          np.array([[[nan, -0.5, -1], [nan, -0.5, -1]], [[nan, -0.5, -0.2], [nan, -0.5, -0.2]]]))
+
+
+@pytest.mark.parametrize(
+    "o,d,expected",
+    [  # tests.py:250-331, sphere radius 1
+        ([-3.0, 0, 0], [1.0, 0, 0], [[-1.0, 0, 0], [1.0, 0, 0]]),
+        ([-3.0, 0, 0], [0.0, 2, 0], [[float("nan")] * 3] * 2),
+        ([-3.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+        ([-3.0, 1, 0], [1.0, 0, 0], [[0.0, 1, 0], [0.0, 1, 0]]),
+        ([1.0, 0, 0], [0.0, 1, 0], [[1.0, 0, 0], [1.0, 0, 0]]),
+        ([0.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+        ([1.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+    ],
+)
+def test_sphere_known_answers(o, d, expected):
+    t, p = O.sphere_intersections(torch.tensor([o]), torch.tensor([d]), torch.tensor([1.0]))
+    assert p.shape == (1, 2, 3) and t.shape == (1, 2)
+    close(p[0], np.array(expected), 1e-6, 1e-6)
+
+
+def test_sphere_output_shape_zero_rays():
+    z = torch.zeros(4, 3)  # tests.py:236-242
+    t, p = O.sphere_intersections(z, z, torch.tensor([2]))
+    assert p.shape == (4, 2, 3)
+
+
+# ---- a3 ---------------------------------------------------------------------------------
+def test_posenc(golden):
+    g = golden("posenc")
+    close(O.posenc(T(g["x3"]), 10), g["e63"], 0, 0)
+    close(O.posenc(T(g["x3"]) / 6.0, 4), g["e27"], 0, 0)
+    close(O.posenc(T(g["x6"]), 10), g["e126"], 0, 0)
+    assert O.posenc_dim(3, 10) == 63 and O.posenc_dim(3, 4) == 27 and O.posenc_dim(6, 10) == 126
+
+
+# ---- a4 ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_depthnet(golden, scenes, scene):
+    g = golden("depthnet")
+    z = O.depthnet_forward(scenes(scene)["depth"], T(g["o"]), T(g["d"]))
+    assert z.shape == (g["o"].shape[0], 1)
+    exp = g[f"z_{scene}"]
+    assert np.isnan(exp[256:258]).all()          # the two rays that miss the sphere
+    assert exp[:256].std() > 0.05                 # the synthetic net is not a constant
+    close(z, exp, 1e-6, 1e-6)
+
+
+def test_depthnet_structure():
+    """Layer structure pinned by tests.py:115-194 (dims of the production configuration)."""
+    p = O.make_depthnet_params(0, n_layers=10, width=256)
+    assert p["origin_layers.0.weight"].shape == (256, 126)
+    assert p["direction_layers.5.weight"].shape == (256, 319)
+    assert p["intersection_layers.0.weight"].shape == (256, 252)
+    assert p["intersection_layers.9.weight"].shape == (256, 382)
+    assert p["cat_layers.0.weight"].shape == (256, 1020)
+    assert p["cat_layers.18.weight"].shape == (256, 256)
+    assert p["to_depth.0.weight"].shape == (1, 256)
+    assert sum(v.numel() for v in p.values()) == 3340545
+
+
+# ---- a5 ---------------------------------------------------------------------------------
+def test_place_samples(golden):
+    g = golden("place_samples")
+    o, d, mean = T(g["o"]), T(g["d"]), T(g["mean"])
+    for n_s in (2, 3, 32, 64):
+        for std in (0.01, 0.1):
+            pts, z = O.place_samples(o, d, mean, n_s, "uniform", std)
+            close(z, g[f"uniform_n{n_s}_s{std}_z"], 0, 0)
+            if n_s <= 3:
+                close(pts, g[f"uniform_n{n_s}_s{std}_pts"], 0, 0)
+    # odd n-1 duplicates the mean sample
+    z3 = g["uniform_n3_s0.1_z"]
+    assert z3.shape[1] == 3
+    pts, z = O.place_samples(o, d, mean, 32, "depth_only", 0.1)
+    close(z, g["depth_only_z"], 0, 0)
+    close(pts, g["depth_only_pts"], 0, 0)
+    pts, z = O.place_samples(o, d, mean, 32, "gaussian", 0.1, noise=T(g["gaussian_noise"]))
+    close(z, g["gaussian_n32_z"], 0, 0)
+    close(pts[:8], g["gaussian_n32_pts_first8"], 0, 0)
+
+
+# ---- a6 / a7 ----------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_nerf_mlp(golden, scenes, scene):
+    g = golden("nerf_mlp")
+    pts, view = T(g["pts"]), T(g["viewdirs"])
+    for which in ("coarse", "fine"):
+        raw = O.run_network(scenes(scene)[which], pts, view)
+        assert raw.shape == (64, 4, 4)
+        close(raw, g[f"raw_{scene}_{which}"], 1e-5, 1e-5)
+    x90 = torch.cat([O.posenc(pts.reshape(-1, 3), 10),
+                     O.posenc(view[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
+    close(O.nerf_forward(scenes(scene)["fine"], x90), g[f"fwd_{scene}_fine"], 1e-5, 1e-5)
+
+
+def test_nerf_param_count():
+    p = O.make_nerf_params(0)
+    assert sum(v.numel() for v in p.values()) == 595844
+    assert p["pts_linears.5.weight"].shape == (256, 319)
+    assert p["views_linears.0.weight"].shape == (128, 283)
+
+
+# ---- a8 ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1, 2, 32, 64, 192])
+@pytest.mark.parametrize("wb", [True, False])
+def test_raw2outputs(golden, N, wb):
+    g = golden("raw2outputs")
+    res = O.raw2outputs(T(g[f"N{N}_raw"]), T(g[f"N{N}_z"]), T(g[f"N{N}_rays_d"]), 0, wb)
+    for nm, v in zip(("rgb", "disp", "acc", "depth", "density", "alphas", "weights"), res):
+        close(v, g[f"N{N}_wb{int(wb)}_{nm}"], 1e-6, 1e-7)
+
+
+def test_raw2outputs_noise(golden):
+    g = golden("raw2outputs")
+    res = O.raw2outputs(T(g["N32_raw"]), T(g["N32_z"]), T(g["N32_rays_d"]), 0.5, True,
+                        noise=T(g["N32_noise"]))
+    close(res[0], g["N32_noisy_rgb"], 1e-6, 1e-7)
+    close(res[6], g["N32_noisy_weights"], 1e-6, 1e-7)
+
+
+# ---- a11 --------------------------------------------------------------------------------
+def test_sample_pdf(golden):
+    g = golden("sample_pdf")
+    bins, w = T(g["bins"]), T(g["weights"])
+    close(O.sample_pdf(bins, w, 128, det=True), g["det"], 0, 0)
+    close(O.sample_pdf(bins, w, 128, det=False, u=T(g["u"])), g["rnd"], 0, 0)
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+@pytest.mark.parametrize("lindisp", [True, False])
+def test_hierarchical(golden, scenes, scene, lindisp):
+    g = golden("hierarchical")
+    sc = scenes(scene)
+    res = O.hierarchical_render(T(g["ray_batch"]), sc["coarse"], sc["fine"], 64, 128, lindisp, True)
+    names = ("density", "z", "pts", "rgb_map", "weights", "alphas", "disp", "raw")
+    for nm, v in zip(names, res):
+        exp = g[f"{scene}_lin{int(lindisp)}_{nm}"]
+        close(v[: exp.shape[0]], exp, 2e-5, 2e-5)
+    assert res[1].shape == (96, 192)
+
+
+def test_hierarchical_perturbed(golden, scenes):
+    g = golden("hierarchical")
+    sc = scenes("tiny_synth")
+    res = O.hierarchical_render(T(g["ray_batch"]), sc["coarse"], sc["fine"], 64, 128, True, True,
+                                perturb=1.0, t_rand=T(g["perturb_t_rand"]), u=T(g["perturb_u"]))
+    close(res[1], g["perturb_z"], 2e-5, 2e-5)
+    close(res[3], g["perturb_rgb_map"], 2e-5, 2e-5)
+    close(res[4], g["perturb_weights"], 2e-5, 2e-5)
+
+
+# ---- a9 ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+@pytest.mark.parametrize("mode", ["depthnet", "full_nerf", "nerf_max", "compare"])
+def test_render_rays_test(golden, scenes, scene, mode):
+    g = golden("render_rays_test")
+    sc = scenes(scene)
+    flags = {"full_nerf": dict(use_full_nerf=True), "nerf_max": dict(use_nerf_max_pts=True),
+             "compare": dict(compare_nerf=True), "depthnet": {}}[mode]
+    res = O.render_rays_test(T(g["ray_batch"]), sc["coarse"], sc["fine"], sc["depth"], 32,
+                             "uniform", 0.1, white_bkgd=True, **flags)
+    prefix = f"{scene}_{mode}_"
+    keys = [k[len(prefix):] for k in g if k.startswith(prefix)]
+    assert set(keys) == set(res.keys())
+    for k in keys:
+        exp = g[prefix + k]
+        assert res[k].shape[1:] == exp.shape[1:], k
+        close(res[k][: exp.shape[0]], exp, 5e-5, 5e-5)
+    if mode == "nerf_max":  # quirk: disp is zeros_like(rgb) -> [R,3] (nerf_utils.py:826)
+        assert res["depth_net_disp_map"].shape == (256, 3)
+
+
+@pytest.mark.parametrize("ns,mode,dist", [(2, "uniform", 0.01), (64, "uniform", 0.1), (1, "depth_only", 0.1)])
+def test_render_rays_test_sampling_setups(golden, scenes, ns, mode, dist):
+    g = golden("render_rays_test")
+    sc = scenes("lego_synth")
+    res = O.render_rays_test(T(g["ray_batch"]), sc["coarse"], sc["fine"], sc["depth"], ns, mode, dist)
+    for k in ("depth_net_rgb_map", "depth_net_disp_map", "depth_net_weights", "depth_net_z_vals"):
+        close(res[k], g[f"lego_synth_{mode}{ns}_{dist}_{k}"], 5e-5, 5e-5)
+
+
+def test_frame_config1(golden, scenes):
+    """BASELINE config 1: 64x64, 32 samples/ray through the render_test chunk driver."""
+    g = golden("frame64")
+    sc = scenes("lego_synth")
+    rgb, disp, extras = O.render_frame(
+        64, 64, g["K"], T(g["c2w"]), 1024 * 32, 2.0, 6.0, p_coarse=sc["coarse"], p_fine=sc["fine"],
+        p_depth=sc["depth"], n_depth_samples=32, sampling_mode="uniform", distance=0.1)
+    assert rgb.shape == (64, 64, 3) and disp.shape == (64, 64)
+    close(rgb, g["rgb"], 5e-5, 5e-5)
+    close(disp, g["disp"], 5e-5, 5e-5)
+    close(extras["depth_net_z_vals"][:, ::8], g["z_vals"], 1e-5, 1e-5)
+    close(extras["depth_net_weights"][::4, ::4], g["weights"], 5e-5, 5e-5)
+    assert g["rgb"].std() > 0.05  # the synthetic scene is not blank
+
+
+# ---- a10 --------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_render_rays_train(golden, scenes, scene):
+    g = golden("render_rays_train")
+    sc = scenes(scene)
+    res = O.render_rays(T(g["ray_batch"]), sc["coarse"], sc["fine"], sc["depth"], white_bkgd=True)
+    for k, v in res.items():
+        close(v, g[f"{scene}_{k}"], 5e-5, 5e-5)

@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference, imported in this container.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz
+
+Inputs are seeded; network weights come from the oracle's deterministic generators
+(``oracle.nerf_oracle.make_scene``) and are loaded into the reference's own
+``NeRF`` / ``DepthNet`` modules with ``load_state_dict``; every stored *output* is produced
+by the reference's code (/root/reference), never by the oracle.  The fixtures are data
+(inputs + expected outputs) and are committed; the reference itself never travels.
+"""
+
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from oracle import nerf_oracle as O  # noqa: E402  (weight generators + camera only)
+from ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def npy(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KB  keys={sorted(arrays)}")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def ref_nerf(ref, params, D, W):
+    net = ref.helpers.NeRF(D=D, W=W, input_ch=63, input_ch_views=27, output_ch=5,
+                           skips=[4], use_viewdirs=True)
+    net.load_state_dict(params)
+    return net.eval()
+
+
+def ref_depthnet(ref, params, n_layers, width, radius=2.0):
+    net = quiet(ref.depth_net.DepthNet, hidden_sizes=[width] * n_layers,
+                cat_hidden_sizes=[width] * n_layers, sphere_radius=radius)
+    net.load_state_dict(params)
+    return net.eval()
+
+
+def make_trainer(ref, **over):
+    kw = dict(dataset_type="blender", basedir="/tmp", expname="golden", no_batching=True,
+              datadir="/nonexistent", half_res=True, white_bkgd=True, N_importance=128,
+              N_samples=64, use_viewdirs=True, input_dims_embed=3, device="cpu")
+    kw.update(over)
+    return quiet(ref.sampling_trainer.DepthNetTrainer, **kw)
+
+
+def render_kwargs(ref, trainer, coarse, fine, depth, perturb=0.0, raw_noise_std=0.0):
+    """The kwargs dict of nerf_utils.create_nerf :471-492 + sampling_trainer :111-115."""
+    embed_fn, _ = ref.helpers.get_embedder(trainer.multires, trainer.i_embed, 3)
+    embeddirs_fn, _ = ref.helpers.get_embedder(trainer.multires_views, trainer.i_embed, 3)
+    query = lambda inputs, viewdirs, network_fn: trainer.run_network(  # noqa: E731
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+        netchunk=trainer.netchunk)
+    return dict(network_query_fn=query, perturb=perturb, N_importance=trainer.N_importance,
+                network_fine=fine, N_samples=trainer.N_samples, network_fn=coarse,
+                use_viewdirs=True, white_bkgd=trainer.white_bkgd, raw_noise_std=raw_noise_std,
+                trainer=trainer, lindisp=trainer.lindisp, depth_network=depth,
+                model_mode="test"), embed_fn, embeddirs_fn
+
+
+def camera(H, W, theta=30.0):
+    focal, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(theta, -30.0, 4.0)[:3, :4]
+    return K, c2w
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = import_reference()
+    g = torch.Generator().manual_seed(1234)
+
+    # ---- a1 rays ------------------------------------------------------------------
+    print("a1 rays")
+    for (H, W, theta, tag) in ((64, 64, 30.0, "64"), (5, 7, -117.0, "5x7")):
+        K, c2w = camera(H, W, theta)
+        ro, rd = ref.helpers.get_rays(H, W, K, c2w)
+        batch, o, d, sh = ref.nerf_utils.prepare_rays(
+            c2w=c2w, c2w_staticcam=None, use_viewdirs=True, ndc=False, H=H, W=W, K=K,
+            near=2.0, far=6.0, rays=None)
+        save(f"rays_{tag}", H=H, W=W, K=K, c2w=c2w, rays_o=ro if H < 10 else ro[:2],
+             rays_d=rd if H < 10 else rd[:2], ray_batch=batch)
+    poses = torch.stack([ref.load_blender.pose_spherical(a, -30.0, 4.0)
+                         for a in np.linspace(-180, 180, 40 + 1)[:-1]], 0)
+    save("poses", render_poses=poses)
+
+    # ---- a2 sphere ----------------------------------------------------------------
+    print("a2 sphere / quadratic")
+    known_o = torch.tensor([[-3., 0, 0], [-3., 0, 0], [-3., 0, 0], [-3., 1, 0], [1., 0, 0],
+                            [0., 0, 0], [1., 0, 0]])
+    known_d = torch.tensor([[1., 0, 0], [0., 2, 0], [-1., 0, 0], [1., 0, 0], [0., 1, 0],
+                            [-1., 0, 0], [-1., 0, 0]])
+    t1, p1 = ref.utils.find_intersection_points_with_sphere(known_o, known_d, torch.tensor([1.0]))
+    o = torch.randn(256, 3, generator=g) * 2.5
+    d = torch.randn(256, 3, generator=g)
+    t2, p2 = ref.utils.find_intersection_points_with_sphere(o, d, torch.tensor([2.0]))
+    qa = torch.tensor([1., 4, 5, 1, 4, 5]); qb = torch.tensor([1., 4, 6, 1, 4, 6])
+    qc = torch.ones(6)
+    qs = ref.utils.solve_quadratic_equation(qa, qb, qc)
+    save("sphere", known_o=known_o, known_d=known_d, known_t=t1, known_p=p1, o=o, d=d, t=t2,
+         p=p2, qa=qa, qb=qb, qc=qc, qs=qs)
+
+    # ---- a3 posenc ----------------------------------------------------------------
+    print("a3 posenc")
+    x3 = torch.cat([torch.rand(60, 3, generator=g) * 12 - 6,
+                    torch.tensor([[6., -6, 0], [0.5, -0.25, 1e-3], [4.0311, 2.0, -3.99],
+                                  [-6, 6, 5.999]])])
+    x6 = torch.rand(64, 6, generator=g) * 4 - 2
+    e63 = ref.helpers.get_embedder(10, 0, 3)[0](x3)
+    e27 = ref.helpers.get_embedder(4, 0, 3)[0](x3 / 6.0)
+    e126 = ref.helpers.get_embedder(10, 0, 6)[0](x6)
+    save("posenc", x3=x3, e63=e63, e27=e27, x6=x6, e126=e126)
+
+    scenes = {n: O.make_scene(n) for n in ("tiny_synth", "lego_synth")}
+    cfgs = {n: O.SCENES[n] for n in scenes}
+    nets = {}
+    for n, sc in scenes.items():
+        c = cfgs[n]
+        nets[n] = dict(
+            coarse=ref_nerf(ref, sc["coarse"], c["coarse"]["D"], c["coarse"]["W"]),
+            fine=ref_nerf(ref, sc["fine"], c["fine"]["D"], c["fine"]["W"]),
+            depth=ref_depthnet(ref, sc["depth"], c["depth"]["n_layers"], c["depth"]["width"]),
+        )
+
+    K64, c2w64 = camera(64, 64)
+    batch64, o64, d64, _ = ref.nerf_utils.prepare_rays(
+        c2w=c2w64, c2w_staticcam=None, use_viewdirs=True, ndc=False, H=64, W=64, K=K64,
+        near=2.0, far=6.0, rays=None)
+    sel = torch.arange(0, 4096, 16)  # 256 rays spread over the 64x64 frame
+
+    with torch.no_grad():
+        # ---- a4 DepthNet ------------------------------------------------------------
+        print("a4 depthnet")
+        o_in, d_in = o64[sel], d64[sel]
+        # add two rays that miss the r=2 sphere (NaN depth) and a free-form batch
+        o_miss = torch.tensor([[0., 0, 4.0], [3., 3, 3]]); d_miss = torch.tensor([[1., 0, 0], [0., 0, 1]])
+        o_free = torch.randn(62, 3, generator=g) * 0.8; d_free = torch.randn(62, 3, generator=g)
+        o_all = torch.cat([o_in, o_miss, o_free]); d_all = torch.cat([d_in, d_miss, d_free])
+        out = {"o": o_all, "d": d_all}
+        for n in scenes:
+            out[f"z_{n}"] = nets[n]["depth"](o_all, d_all)
+        save("depthnet", **out)
+
+        # ---- a5 sample placement ------------------------------------------------------
+        print("a5 place_samples")
+        mean = nets["lego_synth"]["depth"](o_in, d_in)
+        mean[3, 0] = 2.004; mean[5, 0] = 5.995  # exercise the clip at 2 / 6
+        out = {"o": o_in, "d": d_in, "mean": mean}
+        for n_s in (2, 3, 32, 64):
+            for std in (0.01, 0.1):
+                pts, z = ref.utils.sample_points_around_mean(o_in, d_in, mean, n_s, "uniform", std)
+                out[f"uniform_n{n_s}_s{std}_z"] = z
+                if n_s <= 3:
+                    out[f"uniform_n{n_s}_s{std}_pts"] = pts
+        pts, z = ref.utils.sample_points_around_mean(o_in, d_in, mean, 32, "depth_only", 0.1)
+        out["depth_only_z"], out["depth_only_pts"] = z, pts
+        torch.manual_seed(77)
+        pts, z = ref.utils.sample_points_around_mean(o_in, d_in, mean, 32, "gaussian", 0.1)
+        torch.manual_seed(77)
+        out["gaussian_noise"] = torch.randn(mean.shape[0], 31)
+        out["gaussian_n32_z"] = z
+        out["gaussian_n32_pts_first8"] = pts[:8]
+        save("place_samples", **out)
+
+        # ---- a6/a7 run_network / NeRF -------------------------------------------------
+        print("a6/a7 nerf mlp")
+        pts_in = (torch.rand(64, 4, 3, generator=g) * 2 - 1) * 3.0
+        view_in = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=-1)
+        out = {"pts": pts_in, "viewdirs": view_in}
+        for n in scenes:
+            tr = make_trainer(ref)
+            kw, embed_fn, embeddirs_fn = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"],
+                                                       nets[n]["depth"])
+            for which in ("coarse", "fine"):
+                out[f"raw_{n}_{which}"] = kw["network_query_fn"](pts_in, view_in, nets[n][which])
+            x90 = torch.cat([embed_fn(pts_in.reshape(-1, 3)),
+                             embeddirs_fn(view_in[:, None].expand(pts_in.shape).reshape(-1, 3))], -1)
+            out[f"fwd_{n}_fine"] = nets[n]["fine"](x90)
+        save("nerf_mlp", **out)
+
+        # ---- a8 raw2outputs -----------------------------------------------------------
+        print("a8 raw2outputs")
+        tr = make_trainer(ref)
+        out = {}
+        for N in (1, 2, 32, 64, 192):
+            R = 48
+            raw = torch.randn(R, N, 4, generator=g)
+            raw[..., 3] = raw[..., 3] * 40.0 + 10.0
+            raw[0, :, 3] = -5.0            # fully transparent ray
+            raw[1, :, 3] = 500.0           # opaque at the first sample
+            raw[2, -1, 3] = -1.0           # last sample (dist 1e10) transparent
+            z = torch.sort(torch.rand(R, N, generator=g) * 4 + 2, -1).values
+            if N > 2:
+                z[3, 1] = z[3, 0]          # duplicated sample -> dist 0
+                z[4] = z[4, :1]            # all samples coincide
+            rd = torch.randn(R, 3, generator=g)
+            for wb in (True, False):
+                res = tr.raw2outputs(raw, z, rd, 0, wb)
+                names = ("rgb", "disp", "acc", "depth", "density", "alphas", "weights")
+                for nm, v in zip(names, res):
+                    out[f"N{N}_wb{int(wb)}_{nm}"] = v
+            out[f"N{N}_raw"], out[f"N{N}_z"], out[f"N{N}_rays_d"] = raw, z, rd
+        # noise path: raw_noise_std > 0 with torch.randn drawn under a known seed
+        raw, z, rd = out["N32_raw"], out["N32_z"], out["N32_rays_d"]
+        torch.manual_seed(5)
+        res = tr.raw2outputs(raw, z, rd, 0.5, True)
+        torch.manual_seed(5)
+        out["N32_noise"] = torch.randn(raw[..., 3].shape)
+        out["N32_noisy_rgb"], out["N32_noisy_weights"] = res[0], res[6]
+        save("raw2outputs", **out)
+
+        # ---- sample_pdf ---------------------------------------------------------------
+        print("a11 sample_pdf")
+        bins = torch.sort(torch.rand(40, 63, generator=g) * 4 + 2, -1).values
+        w = torch.rand(40, 62, generator=g) ** 4
+        w[0] = 0.0                          # flat pdf
+        w[1] = 0.0; w[1, 17] = 1.0          # single spike
+        det = ref.helpers.sample_pdf(bins, w, 128, det=True)
+        torch.manual_seed(9)
+        rnd = ref.helpers.sample_pdf(bins, w, 128, det=False)
+        torch.manual_seed(9)
+        u = torch.rand(40, 128)
+        save("sample_pdf", bins=bins, weights=w, det=det, u=u, rnd=rnd)
+
+        # ---- a11 hierarchical path ----------------------------------------------------
+        print("a11 hierarchical")
+        rb = batch64[sel][:96]
+        out = {"ray_batch": rb}
+        names8 = ("density", "z", "pts", "rgb_map", "weights", "alphas", "disp", "raw")
+        for n in scenes:
+            for lindisp in (True, False):
+                tr = make_trainer(ref, lindisp=lindisp)
+                kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+                res = ref.nerf_utils.sample_as_in_NeRF(
+                    ray_batch=rb, network_fn=kw["network_fn"], network_fine=kw["network_fine"],
+                    network_query_fn=kw["network_query_fn"], N_samples=64, trainer=tr, perturb=0.0,
+                    raw_noise_std=0.0, lindisp=lindisp, white_bkgd=True, kwargs={}, pytest=False)
+                for nm, v in zip(names8, res):
+                    if nm in ("pts", "raw", "density", "alphas") and n == "lego_synth":
+                        v = v[:8]
+                    out[f"{n}_lin{int(lindisp)}_{nm}"] = v
+        # stratified jitter + random inverse-CDF draws under a known seed (perturb=1)
+        tr = make_trainer(ref, lindisp=True)
+        kw, _, _ = render_kwargs(ref, tr, nets["tiny_synth"]["coarse"], nets["tiny_synth"]["fine"],
+                                 nets["tiny_synth"]["depth"])
+        torch.manual_seed(31)
+        res = ref.nerf_utils.sample_as_in_NeRF(
+            ray_batch=rb, network_fn=kw["network_fn"], network_fine=kw["network_fine"],
+            network_query_fn=kw["network_query_fn"], N_samples=64, trainer=tr, perturb=1.0,
+            raw_noise_std=0.0, lindisp=True, white_bkgd=True, kwargs={}, pytest=False)
+        torch.manual_seed(31)
+        out["perturb_t_rand"] = torch.rand(rb.shape[0], 64)
+        out["perturb_u"] = torch.rand(rb.shape[0], 128)
+        out["perturb_z"], out["perturb_rgb_map"], out["perturb_weights"] = res[1], res[3], res[4]
+        save("hierarchical", **out)
+
+        # ---- a9 render_rays_test ------------------------------------------------------
+        print("a9 render_rays_test")
+        rb = batch64[sel]
+        out = {"ray_batch": rb}
+        for n in scenes:
+            for mode, flags in (("depthnet", {}), ("full_nerf", {"use_full_nerf": True}),
+                                ("nerf_max", {"use_nerf_max_pts": True}),
+                                ("compare", {"compare_nerf": True})):
+                tr = make_trainer(ref, n_depth_samples=32, sampling_mode="uniform", distance=0.1, **flags)
+                kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+                res = ref.nerf_utils.render_rays_test(rb, **kw)
+                for k, v in res.items():
+                    if n == "lego_synth" and k in ("depth_net_pts", "max_pts"):
+                        v = v[:16]
+                    if mode == "full_nerf" and k in ("depth_net_weights", "depth_net_z_vals", "depth_net_pts"):
+                        v = v[:16]
+                    out[f"{n}_{mode}_{k}"] = v
+        # other sampling set-ups of the DepthNet branch (lego_synth)
+        n = "lego_synth"
+        for (ns, mode, dist) in ((2, "uniform", 0.01), (64, "uniform", 0.1), (1, "depth_only", 0.1)):
+            tr = make_trainer(ref, n_depth_samples=ns, sampling_mode=mode, distance=dist)
+            kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+            res = ref.nerf_utils.render_rays_test(rb, **kw)
+            for k in ("depth_net_rgb_map", "depth_net_disp_map", "depth_net_weights", "depth_net_z_vals"):
+                out[f"{n}_{mode}{ns}_{dist}_{k}"] = res[k]
+        save("render_rays_test", **out)
+
+        # ---- BASELINE config 1: 64x64 frame, 32 samples/ray, through render_test ------
+        print("config1 frame 64x64")
+        tr = make_trainer(ref, n_depth_samples=32, sampling_mode="uniform", distance=0.1)
+        kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+        kw.update(near=2.0, far=6.0, ndc=False)  # nerf_utils.py:485-488, sampling_trainer.py:60-65
+        rgb, disp, extras = ref.nerf_utils.render_test(64, 64, K64, chunk=1024 * 32, c2w=c2w64, **kw)
+        save("frame64", H=64, W=64, K=K64, c2w=c2w64, rgb=rgb, disp=disp,
+             z_vals=extras["depth_net_z_vals"][:, ::8], weights=extras["depth_net_weights"][::4, ::4])
+
+        # ---- a10 render_rays (training operator, forward) -----------------------------
+        print("a10 render_rays")
+        rb = batch64[sel][:64]
+        out = {"ray_batch": rb}
+        for n in scenes:
+            tr = make_trainer(ref)
+            kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+            res = ref.nerf_utils.render_rays(rb, **kw)
+            for k, v in res.items():
+                out[f"{n}_{k}"] = v
+        save("render_rays_train", **out)
+
+    if "--stats" in sys.argv:
+        w = out  # noqa
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print(f"total {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
