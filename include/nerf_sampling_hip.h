@@ -1,0 +1,179 @@
+/*
+ * nerf_sampling_hip.h -- C ABI of libnerf_sampling_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of MarcinKadziolka/nerf-sampling: the ray-batch render
+ * operator (ray generation, ray-sphere intersection, positional encoding, DepthNet and
+ * radiance-field MLP forward, alpha compositing).  The reference has no native code, so
+ * each entry point below names the reference *Python* function (file:line relative to the
+ * reference tree) whose arithmetic it replaces; a ctypes binding for every one of them is in
+ * nerf_sampling_amd/_lib.py and the reference-side stub is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer, fp32 unless stated; caller-owned
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
+ *     asynchronous on it and re-entrant across streams
+ *   - return value: 0 = ok, negative = NS_E_* below (nothing was launched), never throws
+ *   - no torch types, no global state except lazily-queried device properties
+ */
+#ifndef NERF_SAMPLING_HIP_H
+#define NERF_SAMPLING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS_OK 0
+#define NS_E_INVALID (-1)     /* bad argument (null pointer, non-positive size, ...)   */
+#define NS_E_UNSUPPORTED (-2) /* network shape outside what the kernels are built for  */
+#define NS_E_HIP (-3)         /* a HIP runtime call failed; see ns_last_error()        */
+#define NS_E_NOMEM (-4)
+
+/* operand precision of the MFMA kernels (accumulation is always fp32) */
+#define NS_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact-fp32 parity path */
+#define NS_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16                        */
+#define NS_DTYPE_F16 2  /* v_mfma_f32_32x32x16_f16                         */
+
+/* sample placement modes, utils.py:220-244 */
+#define NS_MODE_DEPTH_ONLY 0
+#define NS_MODE_UNIFORM 1
+#define NS_MODE_GAUSSIAN 2
+
+const char* ns_last_error(void);
+int ns_version(void);
+/* number of compute units of the current device (0 if no device) */
+int ns_device_cu_count(void);
+
+/* ---- a1  get_rays + prepare_rays  (run_nerf_helpers.py:187-202, nerf_utils.py:156-188) ----
+ * Pixel rows [row0,row1) of an HxW pinhole camera, row-major.  c2w is 12 HOST floats (3x4,
+ * row-major).  Any output pointer may be NULL.  ray_batch is [R,11] =
+ * [o(3) d(3) near far viewdir(3)], viewdir = d/|d|; R = (row1-row0)*W.                      */
+int ns_get_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w_host,
+                int row0, int row1, float near_, float far_, float* rays_o_dev, float* rays_d_dev,
+                float* viewdirs_dev, float* ray_batch_dev, void* stream);
+
+/* ---- a2  find_intersection_points_with_sphere / solve_quadratic_equation (utils.py:159-217)
+ * t [R,2] (minus-sqrt root first) and points [R,2,3]; NaN where the line misses the sphere.  */
+int ns_sphere_intersect(const float* o_dev, const float* d_dev, int64_t R, float radius,
+                        float* t_dev, float* pts_dev, void* stream);
+/* element-wise quadratic roots: out [2,n] */
+int ns_solve_quadratic(const float* a_dev, const float* b_dev, const float* c_dev, int64_t n,
+                       float* out_dev, void* stream);
+
+/* ---- a3  Embedder.embed (run_nerf_helpers.py:15-63): x [M,d] -> [M, d*(1+2L)] ------------- */
+int ns_posenc(const float* x_dev, int64_t M, int d, int n_freqs, float* out_dev, void* stream);
+
+/* ---- packed network weights ------------------------------------------------------------
+ * Host-side packers: take the reference state-dict tensors (HOST fp32, row-major
+ * [out,in] weights as nn.Linear stores them) and build the device-resident MFMA weight
+ * stream.  Handles own device memory; destroy with ns_weights_destroy.                      */
+typedef struct ns_weights ns_weights; /* opaque */
+
+/* NeRF(D, W, input_ch=63, input_ch_views=27, skips=[skip], use_viewdirs=True)
+ * (run_nerf_helpers.py:67-134).  w/b: arrays of D + 4 host pointers in the order
+ * pts_linears.0..D-1, feature_linear, alpha_linear, views_linears.0, rgb_linear.
+ * skip = index i after which the embedded input is re-concatenated (4), or -1 for none.     */
+int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* const* b, int dtype,
+                 ns_weights** out);
+/* DepthNet(hidden_sizes=[width]*n_layers, cat_hidden_sizes=[width]*n_layers, multires=10)
+ * (depth_net.py:10-169).  w/b: 4*n_layers + 1 host pointers in the order origin_layers.0..,
+ * direction_layers.0.., intersection_layers.0.., cat_layers.0,2,.., to_depth.0.              */
+int ns_pack_depthnet(int n_layers, int width, const float* const* w, const float* const* b,
+                     int dtype, ns_weights** out);
+void ns_weights_destroy(ns_weights* w);
+/* bytes of the device weight stream (for roofline accounting) */
+int64_t ns_weights_stream_bytes(const ns_weights* w);
+
+/* ---- a4  DepthNet.forward (depth_net.py:117-169): (o,d) [R,3] -> z [R] in [near,far] -------- */
+int ns_depthnet_forward(const ns_weights* net, const float* o_dev, const float* d_dev, int64_t R,
+                        float near_, float far_, float sphere_radius, float* z_dev, void* stream);
+
+/* ---- a5  sample_points_around_mean (utils.py:220-244) ---------------------------------------
+ * mean [R]; noise [R,N-1] standard-normal draws (GAUSSIAN only, else NULL); outputs z [R,N]
+ * and pts [R,N,3] (either may be NULL).  DEPTH_ONLY ignores N (treated as 1).               */
+int ns_place_samples(int mode, const float* o_dev, const float* d_dev, const float* mean_dev,
+                     const float* noise_dev, int64_t R, int N, float std_, float* pts_dev,
+                     float* z_dev, void* stream);
+
+/* ---- a6+a7  Trainer.run_network + NeRF.forward (Trainer.py:789-806, helpers :67-134) --------
+ * pts [R,N,3], viewdirs [R,3] -> raw [R,N,4] = (rgb pre-sigmoid, sigma pre-relu).
+ * If pts_dev is NULL the points are formed in-kernel as o + d*z from o,d [R,3], z [R,N].     */
+int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_dev,
+                    const float* d_dev, const float* z_dev, const float* viewdirs_dev, int64_t R,
+                    int N, float* raw_dev, void* stream);
+/* NeRF.forward on an already embedded input x [M,90] -> [M,4] */
+int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t M, float* raw_dev,
+                             void* stream);
+
+/* ---- a8  raw2alpha + DepthNetTrainer.raw2outputs (nerf_utils.py:27-42, sampling_trainer.py
+ * :153-230).  raw [R,N,4], z [R,N], rays_d [R,3]; noise [R,N] already multiplied by
+ * raw_noise_std, or NULL.  Outputs (any may be NULL): rgb [R,3], disp/acc/depth [R],
+ * alphas/weights [R,N].  (density is raw[...,3], a view, and has no output here.)          */
+int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d_dev,
+                   const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
+                   float* disp_dev, float* acc_dev, float* depth_dev, float* alphas_dev,
+                   float* weights_dev, void* stream);
+
+/* ---- a11 vanilla hierarchical pieces (Trainer.py:579-710, run_nerf_helpers.py:250-293) ------ */
+/* stratified coarse depths: near/far [R]; t_rand [R,N] uniform draws or NULL (perturb==0)    */
+int ns_coarse_z(const float* near_dev, const float* far_dev, int64_t R, int N, int lindisp,
+                const float* t_rand_dev, float* z_dev, void* stream);
+/* inverse-CDF sampling: bins [R,Nb], weights [R,Nb-1], u [R,Nf] or NULL (= linspace(0,1,Nf)) */
+int ns_sample_pdf(const float* bins_dev, const float* weights_dev, int64_t R, int Nb, int Nf,
+                  const float* u_dev, float* samples_dev, void* stream);
+/* z_mid + sample_pdf(weights[1:-1]) + sort(cat[z, samples]) in one pass: z [R,Nc],
+ * weights [R,Nc] -> z_out [R,Nc+Nf] ascending (Trainer.py:672-685)                         */
+int ns_importance_z(const float* z_dev, const float* weights_dev, int64_t R, int Nc, int Nf,
+                    const float* u_dev, float* z_out_dev, void* stream);
+/* ascending sort of every row of x [R,N] (torch.sort(x,-1).values), N <= 2048 */
+int ns_sort_rows(const float* x_dev, int64_t R, int N, float* out_dev, void* stream);
+/* pts = o + d*z : o,d [R,3], z [R,N] -> [R,N,3] */
+int ns_points_along_rays(const float* o_dev, const float* d_dev, const float* z_dev, int64_t R,
+                         int N, float* pts_dev, void* stream);
+/* per-ray argmax of weights [R,N] and the gathered z / weight / sigmoid(raw rgb)
+ * (nerf_utils.py:813-819); any output may be NULL                                           */
+int ns_argmax_gather(const float* weights_dev, const float* z_dev, const float* raw_dev, int64_t R,
+                     int N, float* max_z_dev, float* max_w_dev, float* max_rgb_dev, void* stream);
+
+/* ---- a9  the DepthNet branch of render_rays_test as one call (nerf_utils.py:836-865) --------
+ * rays come either from (o,d,viewdirs) device arrays or, if o_dev is NULL, are generated in
+ * place from the camera (rows [row0,row1) of an HxW image).  Runs DepthNet -> placement ->
+ * NeRF MLP -> compositing on `stream` with intermediates in the caller-provided workspace.
+ * Outputs rgb [R,3], disp [R] always; z/weights/pts (per-sample extras) only if non-NULL.   */
+typedef struct ns_render_args {
+  const ns_weights* depthnet;
+  const ns_weights* nerf;
+  /* rays: explicit ... */
+  const float* o_dev;
+  const float* d_dev;
+  const float* viewdirs_dev;
+  int64_t R;
+  /* ... or camera (used when o_dev == NULL) */
+  int H, W, row0, row1;
+  float fx, fy, cx, cy;
+  float c2w[12];
+  /* sampling set-up */
+  int mode;    /* NS_MODE_* */
+  int N;       /* trainer.n_depth_samples */
+  float std_;  /* trainer.distance */
+  const float* noise_dev; /* [R,N-1], GAUSSIAN only */
+  float near_, far_, sphere_radius;
+  int white_bkgd;
+  /* workspace: ns_render_workspace_bytes(R,N) bytes of device memory */
+  void* workspace_dev;
+  /* outputs */
+  float* rgb_dev;
+  float* disp_dev;
+  float* z_dev;       /* [R,N] or NULL */
+  float* weights_dev; /* [R,N] or NULL */
+  float* pts_dev;     /* [R,N,3] or NULL */
+} ns_render_args;
+int64_t ns_render_workspace_bytes(int64_t R, int N);
+int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_SAMPLING_HIP_H */

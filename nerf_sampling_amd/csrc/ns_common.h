@@ -1,0 +1,56 @@
+// Shared host-side helpers for libnerf_sampling_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nerf_sampling_hip.h"
+
+namespace ns {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ceil-div on 64-bit sizes
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid for grid-stride elementwise kernels: enough blocks to fill 256 CUs x 8, capped
+inline int ew_grid(int64_t n, int block) {
+  int64_t g = cdiv(n, block);
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return static_cast<int>(g);
+}
+
+int cu_count();
+
+}  // namespace ns
+
+#define NS_REQUIRE(cond, msg)                    \
+  do {                                           \
+    if (!(cond)) {                               \
+      ns::set_error("%s: %s", __func__, msg);    \
+      return NS_E_INVALID;                       \
+    }                                            \
+  } while (0)
+
+#define NS_HIP(call)                                                           \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      ns::set_error("%s: %s -> %s", __func__, #call, hipGetErrorString(e_));   \
+      return NS_E_HIP;                                                         \
+    }                                                                          \
+  } while (0)
+
+#define NS_LAUNCH_CHECK()                                                      \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      ns::set_error("%s: launch -> %s", __func__, hipGetErrorString(e_));      \
+      return NS_E_HIP;                                                         \
+    }                                                                          \
+  } while (0)

@@ -1,0 +1,324 @@
+// Per-ray scan/search kernels: alpha compositing (raw2outputs), inverse-CDF importance
+// sampling, per-ray argmax.  HBM-bound: every sample is read once (16 B raw + 4 B z) and the
+// per-sample outputs written once; the transmittance product is a wave-level segmented scan.
+#include "ns_common.h"
+
+namespace {
+
+__device__ __forceinline__ float linspace01(int steps, int i) {
+  if (steps <= 1) return 0.0f;
+  const float step = 1.0f / static_cast<float>(steps - 1);
+  return (i < steps / 2) ? step * static_cast<float>(i) : 1.0f - step * static_cast<float>(steps - i - 1);
+}
+
+// a8: nerf_utils.py:27-42 + sampling_trainer.py:153-230.
+// SW lanes cooperate on one ray (SW = power of two <= 64); rays longer than SW samples are
+// walked in chunks of SW with the transmittance carried in a register.
+template <int SW>
+__global__ void __launch_bounds__(256)
+raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
+                   const float* __restrict__ rays_d, const float* __restrict__ noise, int64_t R, int N,
+                   int white_bkgd, float* __restrict__ rgb_out, float* __restrict__ disp_out,
+                   float* __restrict__ acc_out, float* __restrict__ depth_out,
+                   float* __restrict__ alphas_out, float* __restrict__ weights_out) {
+  constexpr int RAYS_PER_BLOCK = 256 / SW;
+  const int sub = threadIdx.x % SW;
+  const int64_t ray_stride = (int64_t)gridDim.x * RAYS_PER_BLOCK;
+  // all lanes of a wave iterate the same number of times (shuffles need full participation)
+  const int64_t iters = (R + ray_stride - 1) / ray_stride;
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t r = it * ray_stride + (int64_t)blockIdx.x * RAYS_PER_BLOCK + threadIdx.x / SW;
+    const bool live = r < R;
+    float norm = 0.f;
+    if (live) {
+      const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+      norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+    }
+    float carry = 1.0f;
+    float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;
+    for (int base = 0; base < N; base += SW) {
+      const int i = base + sub;
+      const bool ok = live && i < N;
+      float alpha = 0.f, zi = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+      if (ok) {
+        const int64_t e = r * N + i;
+        const float4 q = raw[e];
+        zi = z[e];
+        const float dist = ((i < N - 1) ? z[e + 1] - zi : 1e10f) * norm;
+        float sigma = q.w;
+        if (noise) sigma += noise[e];
+        alpha = 1.0f - expf(-fmaxf(sigma, 0.0f) * dist);
+        if (sigma != sigma) alpha = sigma;  // relu(NaN) is NaN in torch
+        cr = 1.0f / (1.0f + expf(-q.x));
+        cg = 1.0f / (1.0f + expf(-q.y));
+        cb = 1.0f / (1.0f + expf(-q.z));
+      }
+      // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this ray
+      float p = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
+#pragma unroll
+      for (int dlt = 1; dlt < SW; dlt <<= 1) {
+        const float up = __shfl_up(p, dlt, SW);
+        if (sub >= dlt) p *= up;
+      }
+      float excl = __shfl_up(p, 1, SW);
+      if (sub == 0) excl = 1.0f;
+      const float T = carry * excl;
+      const float w = alpha * T;
+      carry = carry * __shfl(p, SW - 1, SW);
+      if (ok) {
+        const int64_t e = r * N + i;
+        if (alphas_out) alphas_out[e] = alpha;
+        if (weights_out) weights_out[e] = w;
+        s_r += w * cr; s_g += w * cg; s_b += w * cb;
+        s_depth += w * zi;
+        s_acc += w;
+      }
+    }
+#pragma unroll
+    for (int m = SW >> 1; m > 0; m >>= 1) {
+      s_r += __shfl_xor(s_r, m, SW); s_g += __shfl_xor(s_g, m, SW); s_b += __shfl_xor(s_b, m, SW);
+      s_depth += __shfl_xor(s_depth, m, SW); s_acc += __shfl_xor(s_acc, m, SW);
+    }
+    if (live && sub == 0) {
+      if (white_bkgd) { s_r += 1.0f - s_acc; s_g += 1.0f - s_acc; s_b += 1.0f - s_acc; }
+      if (rgb_out) { rgb_out[r * 3] = s_r; rgb_out[r * 3 + 1] = s_g; rgb_out[r * 3 + 2] = s_b; }
+      if (acc_out) acc_out[r] = s_acc;
+      if (depth_out) depth_out[r] = s_depth;
+      if (disp_out) {
+        const float q = s_depth / (s_acc + 1e-10f);
+        // torch.max(1e-10, q) propagates NaN
+        disp_out[r] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+      }
+    }
+  }
+}
+
+// ---- inverse-CDF sampling, run_nerf_helpers.py:250-293 -----------------------------------------
+// shared body: cdf (length nb) from weights (length nb-1), then one inverse lookup
+constexpr int kMaxBins = 512;
+
+__device__ __forceinline__ void build_cdf(const float* w, int nb, float* pdf_s, float* cdf_s, int lane) {
+  // pdf = (w + 1e-5) / sum;  cdf = [0, cumsum(pdf)]  (cumsum accumulated in double, as ATen's
+  // CPU cumsum does for float input)
+  float part = 0.f;
+  for (int k = lane; k < nb - 1; k += 64) {
+    const float v = w[k] + 1e-5f;
+    pdf_s[k] = v;
+    part += v;
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+  __syncthreads();
+  if (lane == 0) {
+    double run = 0.0;
+    cdf_s[0] = 0.0f;
+    for (int k = 0; k < nb - 1; ++k) {
+      run += static_cast<double>(pdf_s[k] / part);
+      cdf_s[k + 1] = static_cast<float>(run);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float invert_cdf(const float* cdf_s, const float* bins_s, int nb, float u) {
+  // idx = searchsorted(cdf, u, right=True): first k with cdf[k] > u
+  int lo = 0, hi = nb;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cdf_s[mid] > u) hi = mid; else lo = mid + 1;
+  }
+  const int below = max(lo - 1, 0);
+  const int above = min(lo, nb - 1);
+  float denom = cdf_s[above] - cdf_s[below];
+  if (denom < 1e-5f) denom = 1.0f;
+  const float t = (u - cdf_s[below]) / denom;
+  return bins_s[below] + t * (bins_s[above] - bins_s[below]);
+}
+
+__global__ void __launch_bounds__(64)
+sample_pdf_kernel(const float* __restrict__ bins, const float* __restrict__ weights, int64_t R, int Nb,
+                  int Nf, const float* __restrict__ u, float* __restrict__ out) {
+  __shared__ float pdf_s[kMaxBins], cdf_s[kMaxBins], bins_s[kMaxBins];
+  const int lane = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    for (int k = lane; k < Nb; k += 64) bins_s[k] = bins[r * Nb + k];
+    build_cdf(weights + r * (Nb - 1), Nb, pdf_s, cdf_s, lane);
+    for (int s = lane; s < Nf; s += 64) {
+      const float uu = u ? u[r * Nf + s] : linspace01(Nf, s);
+      out[r * Nf + s] = invert_cdf(cdf_s, bins_s, Nb, uu);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ bool sort_less(float a, float b) {
+  return !(a != a) && ((b != b) || a < b);
+}
+
+// Trainer.py:672-685: z_mid, sample_pdf(z_mid, w[1:-1]), sort(cat[z, samples])
+template <int P>
+__global__ void __launch_bounds__(64)
+importance_z_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t R, int Nc, int Nf,
+                    const float* __restrict__ u, float* __restrict__ out) {
+  __shared__ float pdf_s[kMaxBins], cdf_s[kMaxBins], bins_s[kMaxBins], buf[P];
+  const int lane = threadIdx.x;
+  const int Nb = Nc - 1;
+  for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    for (int k = lane; k < Nc; k += 64) buf[k] = z[r * Nc + k];
+    __syncthreads();
+    for (int k = lane; k < Nb; k += 64) bins_s[k] = 0.5f * (buf[k + 1] + buf[k]);
+    build_cdf(w + r * Nc + 1, Nb, pdf_s, cdf_s, lane);
+    for (int s = lane; s < Nf; s += 64) {
+      const float uu = u ? u[r * Nf + s] : linspace01(Nf, s);
+      buf[Nc + s] = invert_cdf(cdf_s, bins_s, Nb, uu);
+    }
+    for (int i = Nc + Nf + lane; i < P; i += 64) buf[i] = __builtin_nanf("");
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < P / 2; t += 64) {
+          const int lo = ((t / j) * 2 * j) + (t % j);
+          const int hi = lo + j;
+          const bool up = ((lo & k) == 0);
+          const float a = buf[lo], b = buf[hi];
+          const bool swap = up ? sort_less(b, a) : sort_less(a, b);
+          if (swap) { buf[lo] = b; buf[hi] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int i = lane; i < Nc + Nf; i += 64) out[r * (Nc + Nf) + i] = buf[i];
+    __syncthreads();
+  }
+}
+
+// nerf_utils.py:813-819: argmax over samples (first index on ties, NaN counts as largest)
+__device__ __forceinline__ bool beats(float v, int i, float bv, int bi) {
+  if (i == 0x7fffffff) return false;
+  if (bi == 0x7fffffff) return true;
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;
+  if (vn) return i < bi;
+  if (v != bv) return v > bv;
+  return i < bi;
+}
+
+__global__ void __launch_bounds__(256)
+argmax_gather_kernel(const float* __restrict__ w, const float* __restrict__ z, const float4* __restrict__ raw,
+                     int64_t R, int N, float* __restrict__ max_z, float* __restrict__ max_w,
+                     float* __restrict__ max_rgb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t r = wave; r < R; r += nwaves) {
+    float best = 0.f;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < N; i += 64) {
+      const float v = w[r * N + i];
+      if (beats(v, i, best, bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const float ov = __shfl_xor(best, m, 64);
+      const int oi = __shfl_xor(bi, m, 64);
+      if (beats(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      if (max_w) max_w[r] = best;
+      if (max_z) max_z[r] = z[r * N + bi];
+      if (max_rgb) {
+        const float4 q = raw[r * N + bi];
+        max_rgb[r * 3] = 1.0f / (1.0f + expf(-q.x));
+        max_rgb[r * 3 + 1] = 1.0f / (1.0f + expf(-q.y));
+        max_rgb[r * 3 + 2] = 1.0f / (1.0f + expf(-q.z));
+      }
+    }
+  }
+}
+
+template <int SW>
+void launch_r2o(const float* raw, const float* z, const float* rays_d, const float* noise, int64_t R, int N,
+                int white, float* rgb, float* disp, float* acc, float* depth, float* alphas, float* weights,
+                hipStream_t s) {
+  const int rays_per_block = 256 / SW;
+  int64_t grid = ns::cdiv(R, rays_per_block);
+  if (grid > 256 * 16) grid = 256 * 16;
+  raw2outputs_kernel<SW><<<static_cast<int>(grid), 256, 0, s>>>(reinterpret_cast<const float4*>(raw), z, rays_d,
+                                                               noise, R, N, white, rgb, disp, acc, depth,
+                                                               alphas, weights);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d_dev,
+                   const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
+                   float* disp_dev, float* acc_dev, float* depth_dev, float* alphas_dev,
+                   float* weights_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 1, "bad shape (N == 0 is handled by the caller)");
+  if (R == 0) return NS_OK;
+  NS_REQUIRE(raw_dev && z_dev && rays_d_dev, "null input");
+  NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  hipStream_t s = ns::as_stream(stream);
+#define NS_R2O(SW) launch_r2o<SW>(raw_dev, z_dev, rays_d_dev, noise_dev, R, N, white_bkgd, rgb_dev, disp_dev, \
+                                  acc_dev, depth_dev, alphas_dev, weights_dev, s)
+  if (N <= 1) NS_R2O(1);
+  else if (N <= 2) NS_R2O(2);
+  else if (N <= 4) NS_R2O(4);
+  else if (N <= 8) NS_R2O(8);
+  else if (N <= 16) NS_R2O(16);
+  else if (N <= 32) NS_R2O(32);
+  else NS_R2O(64);
+#undef NS_R2O
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_sample_pdf(const float* bins_dev, const float* weights_dev, int64_t R, int Nb, int Nf,
+                  const float* u_dev, float* samples_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && Nb >= 2 && Nf >= 0, "bad shape");
+  NS_REQUIRE(Nb <= kMaxBins, "more than 512 bins is not supported");
+  if (R == 0 || Nf == 0) return NS_OK;
+  NS_REQUIRE(bins_dev && weights_dev && samples_dev, "null pointer");
+  const int grid = static_cast<int>(R < 256 * 32 ? R : 256 * 32);
+  sample_pdf_kernel<<<grid, 64, 0, ns::as_stream(stream)>>>(bins_dev, weights_dev, R, Nb, Nf, u_dev, samples_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_importance_z(const float* z_dev, const float* weights_dev, int64_t R, int Nc, int Nf,
+                    const float* u_dev, float* z_out_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && Nc >= 3 && Nf >= 0, "bad shape (needs at least 3 coarse samples)");
+  NS_REQUIRE(Nc - 1 <= kMaxBins && Nc + Nf <= 2048, "sample counts too large");
+  if (R == 0) return NS_OK;
+  NS_REQUIRE(z_dev && weights_dev && z_out_dev, "null pointer");
+  const int grid = static_cast<int>(R < 256 * 32 ? R : 256 * 32);
+  hipStream_t s = ns::as_stream(stream);
+  const int tot = Nc + Nf;
+  if (tot <= 64) importance_z_kernel<64><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  else if (tot <= 128) importance_z_kernel<128><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  else if (tot <= 256) importance_z_kernel<256><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  else if (tot <= 512) importance_z_kernel<512><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  else if (tot <= 1024) importance_z_kernel<1024><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  else importance_z_kernel<2048><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_argmax_gather(const float* weights_dev, const float* z_dev, const float* raw_dev, int64_t R,
+                     int N, float* max_z_dev, float* max_w_dev, float* max_rgb_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 1, "bad shape");
+  if (R == 0) return NS_OK;
+  NS_REQUIRE(weights_dev, "null weights");
+  NS_REQUIRE(!max_z_dev || z_dev, "max_z requested without z");
+  NS_REQUIRE(!max_rgb_dev || raw_dev, "max_rgb requested without raw");
+  int64_t grid = ns::cdiv(R, 4);
+  if (grid > 256 * 16) grid = 256 * 16;
+  argmax_gather_kernel<<<static_cast<int>(grid), 256, 0, ns::as_stream(stream)>>>(
+      weights_dev, z_dev, reinterpret_cast<const float4*>(raw_dev), R, N, max_z_dev, max_w_dev, max_rgb_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+}  // extern "C"

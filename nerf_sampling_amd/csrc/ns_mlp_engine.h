@@ -1,0 +1,346 @@
+// Fused-MLP engine for gfx950: activations stay in registers, weights stream through LDS.
+//
+// Design (MI355X-first, see DESIGN.md "MLP engine"):
+//   * One wave owns a tile of 32 samples for the whole network.  Every layer is computed
+//     TRANSPOSED, Y^T[n, m] = W[n, k] . X^T[k, m], with v_mfma_f32_32x32x{16_bf16,16_f16,2_f32}:
+//     the weight block is the A operand (32 output features x K), the activations are the B
+//     operand (K x 32 samples).  A 32x32 fp32 result then has its sample on the lane and its
+//     feature index in the 16 accumulator registers, which is exactly the B-operand layout of
+//     the next layer's MFMA -- activations never leave the register file, there is no LDS
+//     round trip and no barrier between layers.
+//   * Weights are pre-packed on the host into 1-KiB "chunks" laid out lane-linearly in the
+//     exact order the MFMAs consume them (ns_pack.hip), so that one
+//     global_load_lds_dwordx4 per wave-instruction lands a chunk in LDS and one conflict-free
+//     ds_read_b128 per lane fetches an A fragment.  Chunks are grouped into 16-KiB slabs; all
+//     waves of a workgroup walk the same slab sequence through a ring of LDS slots with ONE
+//     s_barrier per slab and counted s_waitcnt vmcnt(N), so the DMA of slab t+2 is in flight
+//     while slab t feeds the matrix cores.
+//   * Within a 32-feature block, lane half h (= lane >> 5) holds the 16 features
+//     k = 32*blk + (q & 3) + 8*(q >> 2) + 4*h, q = 0..15  (the MFMA C/D register map).  The
+//     host packer applies the same map to the weight columns, so any per-lane assignment of
+//     embedding features to (blk, q, h) is legal as long as both sides agree.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+#include <utility>
+
+namespace nsmlp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kChunkBytes = 1024;
+constexpr int kSlabChunks = 16;
+constexpr int kSlabBytes = kChunkBytes * kSlabChunks;
+constexpr int kRingDepth = 3;
+
+// ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
+template <int... I, class F>
+__host__ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// ---- operand traits --------------------------------------------------------------------------
+// CPB = chunks per 32-feature input block; Block = one lane's 16 features of a 32-feature block.
+struct MmaBF16 {
+  static constexpr int kDtype = 1;
+  static constexpr int CPB = 2;
+  static constexpr int kElemBytes = 2;
+  struct Block { bf16x8 v[2]; };
+  __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b.v[0][j] = (__bf16)x[j]; b.v[1][j] = (__bf16)x[8 + j]; }
+  }
+  template <int SUB>
+  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_lds);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.v[SUB], acc, 0, 0, 0);
+  }
+};
+
+struct MmaF16 {
+  static constexpr int kDtype = 2;
+  static constexpr int CPB = 2;
+  static constexpr int kElemBytes = 2;
+  struct Block { f16x8 v[2]; };
+  __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { b.v[0][j] = (_Float16)x[j]; b.v[1][j] = (_Float16)x[8 + j]; }
+  }
+  template <int SUB>
+  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(a_lds);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.v[SUB], acc, 0, 0, 0);
+  }
+};
+
+struct MmaF32 {
+  static constexpr int kDtype = 0;
+  static constexpr int CPB = 4;
+  static constexpr int kElemBytes = 4;
+  struct Block { float v[16]; };
+  __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) b.v[j] = x[j];
+  }
+  template <int SUB>
+  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(a_lds);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b.v[4 * SUB + e], acc, 0, 0, 0);
+  }
+};
+
+// slabs a segment of NBLK input blocks occupies when feeding NBO output blocks
+__host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
+  const int kps = kSlabChunks / nbo;
+  return (nblk * cpb + kps - 1) / kps;
+}
+
+// ---- LDS weight ring --------------------------------------------------------------------------
+#define NS_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+#define NS_GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
+
+template <int NWAVES>
+struct Ring {
+  static constexpr int LPW = kSlabChunks / NWAVES;  // DMA instructions per wave per slab
+  const char* stream;   // device weight stream, n_slabs * 16 KiB
+  char* lds;            // ring base in LDS (kRingDepth slots)
+  uint32_t n_slabs;
+  uint32_t issue_slab;  // next slab of the stream to fetch (wraps: the stream is cyclic per tile)
+  uint32_t issue_slot;
+  uint32_t read_slot;
+  int wave, lane;
+
+  __device__ __forceinline__ void init(const char* stream_, char* lds_, uint32_t n_slabs_, int wave_,
+                                       int lane_) {
+    stream = stream_; lds = lds_; n_slabs = n_slabs_; wave = wave_; lane = lane_;
+    issue_slab = 0; issue_slot = 0; read_slot = 0;
+#pragma unroll
+    for (int s = 0; s < kRingDepth - 1; ++s) issue();
+  }
+
+  __device__ __forceinline__ void issue() {
+    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + lane * 16;
+    char* dst = lds + issue_slot * kSlabBytes;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int chunk = i * NWAVES + wave;
+      __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src + chunk * kChunkBytes),
+                                       NS_LDS_PTR(dst + chunk * kChunkBytes), 16, 0, 0);
+    }
+    issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
+    issue_slot = (issue_slot + 1 == kRingDepth) ? 0u : issue_slot + 1;
+  }
+
+  // Make the next slab readable and start the fetch of the one kRingDepth-1 ahead.
+  // Returns this lane's read pointer into the slab (chunk c is at +c*1024).
+  __device__ __forceinline__ const char* advance() {
+    // (1) my own DMA pieces of the slab about to be read have landed: only the
+    //     (kRingDepth-2) younger slabs' pieces may still be in flight.  lgkmcnt(0): every
+    //     ds_read of the previous slab has returned before its slot can be refilled.
+    if constexpr (LPW * (kRingDepth - 2) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (LPW * (kRingDepth - 2) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (2) ... and everyone else's; all waves are also done with the previous slab
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (3) refill the slot the previous slab occupied
+    issue();
+    const char* p = lds + read_slot * kSlabBytes + lane * 16;
+    read_slot = (read_slot + 1 == kRingDepth) ? 0u : read_slot + 1;
+    return p;
+  }
+
+  __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+};
+
+// ---- one K-segment of a layer: acc[NBO] += W[:, segment] . in[NBLK] -----------------------------
+template <class M, int NBO, int NBLK, int NWAVES>
+__device__ __forceinline__ void consume(Ring<NWAVES>& ring, f32x16 (&acc)[NBO],
+                                        const typename M::Block (&in)[NBLK]) {
+  constexpr int KPS = kSlabChunks / NBO;         // chunk rows (K steps) per slab
+  constexpr int CHUNKS = NBLK * M::CPB;          // real chunk rows of this segment
+  constexpr int SLABS = (CHUNKS + KPS - 1) / KPS;
+  static_for<SLABS>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    const char* p = ring.advance();
+    static_for<KPS>([&](auto kk_) {
+      constexpr int kk = decltype(kk_)::value;
+      constexpr int kc = s * KPS + kk;
+      if constexpr (kc < CHUNKS) {
+        static_for<NBO>([&](auto nb_) {
+          constexpr int nb = decltype(nb_)::value;
+          M::template mma<kc % M::CPB>(acc[nb], p + (kk * NBO + nb) * kChunkBytes, in[kc / M::CPB]);
+        });
+      }
+    });
+  });
+}
+
+// ---- bias init / activation epilogue ------------------------------------------------------------
+// bias_lds: floats laid out [nb][h][16] for this layer
+template <int NBO>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NBO], const float* bias_lds, int h) {
+  static_for<NBO>([&](auto nb_) {
+    constexpr int nb = decltype(nb_)::value;
+    const f32x4* b = reinterpret_cast<const f32x4*>(bias_lds + nb * 32 + h * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = b[g];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[nb][4 * g + e] = v[e];
+    }
+  });
+}
+
+enum Act { kNone = 0, kRelu = 1, kLeaky = 2 };
+
+template <class M, int ACT, int NBO>
+__device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f32x16 (&acc)[NBO]) {
+  static_for<NBO>([&](auto nb_) {
+    constexpr int nb = decltype(nb_)::value;
+    float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[nb][r];
+      if constexpr (ACT == kRelu) v = fmaxf(v, 0.0f);
+      if constexpr (ACT == kLeaky) v = v > 0.0f ? v : 0.01f * v;
+      x[r] = v;
+    }
+    M::from_f32(out[nb], x);
+  });
+}
+
+// ---- positional-encoding slots -------------------------------------------------------------------
+// Lane half h = 0 evaluates sines, h = 1 cosines of the same argument (cos x = sin(x + pi/2)),
+// so both halves run the same instruction stream.
+struct Rev {  // x / (2 pi) as an unevaluated fp32 pair, for the fast path
+  float hi, lo;
+};
+__device__ __forceinline__ Rev to_rev(float x) {
+  // 1/(2 pi) = 0.15915494309189535 = c_hi + c_lo with c_hi = fl32(1/(2 pi))
+  constexpr float c_hi = 0.15915493667125702f;
+  constexpr float c_lo = 6.4206382432985265e-09f;
+  const float hi = x * c_hi;
+  const float err = __builtin_fmaf(x, c_hi, -hi);  // exact rounding error of the product
+  const float lo = __builtin_fmaf(x, c_lo, err);
+  return {hi, lo};
+}
+
+// PRECISE = false: v_sin_f32 on the reduced argument (16-bit operand paths: its error is far
+// below the operand rounding).  PRECISE = true: odd degree-11 polynomial on [-pi/2, pi/2], ~1e-7
+// absolute -- the same class as the 1-ulp vector sin of the reference's CPU path.  Both reduce
+// the argument exactly: frequencies are powers of two (run_nerf_helpers.py:32), so
+// fract(2^L * x/(2 pi)) is computed without rounding from a two-float x/(2 pi).
+template <bool PRECISE>
+struct Trig {
+  Rev r;
+  __device__ __forceinline__ explicit Trig(float x_) : r(to_rev(x_)) {}
+  // sin(2^level x) for h = 0, cos(2^level x) for h = 1
+  __device__ __forceinline__ float operator()(int level, int h) const {
+    const float scale = __builtin_ldexpf(1.0f, level);
+    const float a = r.hi * scale;                    // exact (power of two)
+    float f = __builtin_amdgcn_fractf(a);            // exact, in [0, 1)
+    const float lo = r.lo * scale + 0.25f * static_cast<float>(h);
+    if constexpr (!PRECISE) {
+      return __builtin_amdgcn_sinf(f + lo);          // v_sin_f32 takes revolutions
+    } else {
+      f = (f >= 0.5f ? f - 1.0f : f) + lo;           // [-0.5, 0.75)
+      f = f > 0.5f ? f - 1.0f : f;                   // [-0.5, 0.5]
+      const float g = (f > 0.25f ? 0.5f - f : (f < -0.25f ? -0.5f - f : f));  // sin(pi - x) = sin x
+      const float x = g * 6.283185307179586f;
+      const float x2 = x * x;
+      float p = -2.5052108385441720e-08f;            // -1/11!
+      p = __builtin_fmaf(p, x2, 2.7557319223985893e-06f);
+      p = __builtin_fmaf(p, x2, -1.9841269841269841e-04f);
+      p = __builtin_fmaf(p, x2, 8.3333333333333332e-03f);
+      p = __builtin_fmaf(p, x2, -1.6666666666666666e-01f);
+      return __builtin_fmaf(p * x2, x, x);
+    }
+  }
+};
+
+// 3-component, L-level embedding into NBLK blocks: slot t = 16*blk + q;
+//   t < 3L: level t/3, component t%3;  then the raw components (h=0: c0,c1; h=1: c2,pad)
+template <class M, bool PRECISE, int L, int NBLK>
+__device__ __forceinline__ void embed3(typename M::Block (&out)[NBLK], const float (&p)[3], int h) {
+  const Trig<PRECISE> t0(p[0]), t1(p[1]), t2(p[2]);
+  static_for<NBLK>([&](auto b_) {
+    constexpr int b = decltype(b_)::value;
+    float x[16];
+    static_for<16>([&](auto q_) {
+      constexpr int t = 16 * b + decltype(q_)::value;
+      constexpr int q = decltype(q_)::value;
+      if constexpr (t < 3 * L) {
+        constexpr int c = t % 3;
+        x[q] = (c == 0 ? t0 : (c == 1 ? t1 : t2))(t / 3, h);
+      } else if constexpr (t == 3 * L) {
+        x[q] = h ? p[2] : p[0];
+      } else if constexpr (t == 3 * L + 1) {
+        x[q] = h ? 0.0f : p[1];
+      } else {
+        x[q] = 0.0f;
+      }
+    });
+    M::from_f32(out[b], x);
+  });
+}
+
+// 6-component, 10-level embedding (DepthNet sphere intersections) into 4 blocks:
+//   t < 60: level t/6, component t%6;  t = 60..62: raw (h=0: c0..c2, h=1: c3..c5);  t = 63: pad
+template <class M, bool PRECISE>
+__device__ __forceinline__ void embed6(typename M::Block (&out)[4], const float (&p)[6], int h) {
+  const Trig<PRECISE> tr[6] = {Trig<PRECISE>(p[0]), Trig<PRECISE>(p[1]), Trig<PRECISE>(p[2]),
+                               Trig<PRECISE>(p[3]), Trig<PRECISE>(p[4]), Trig<PRECISE>(p[5])};
+  static_for<4>([&](auto b_) {
+    constexpr int b = decltype(b_)::value;
+    float x[16];
+    static_for<16>([&](auto q_) {
+      constexpr int q = decltype(q_)::value;
+      constexpr int t = 16 * b + q;
+      if constexpr (t < 60) x[q] = tr[t % 6](t / 6, h);
+      else if constexpr (t < 63) x[q] = h ? p[3 + t - 60] : p[t - 60];
+      else x[q] = 0.0f;
+    });
+    M::from_f32(out[b], x);
+  });
+}
+
+// ---- host/device shared description of the embedding column maps --------------------------------
+// reference column (run_nerf_helpers.py:44-45 order) held by virtual feature k of an embedding
+// segment, or -1 for padding.  k = 32*blk + (q&3) + 8*(q>>2) + 4*h.
+__host__ __device__ inline void k_to_bqh(int k, int& blk, int& q, int& h) {
+  blk = k >> 5;
+  const int r = k & 31;
+  h = (r >> 2) & 1;
+  q = (r & 3) + 4 * (r >> 3);
+}
+__host__ __device__ inline int embed3_col(int k, int L) {
+  int blk, q, h;
+  k_to_bqh(k, blk, q, h);
+  const int t = 16 * blk + q;
+  if (t < 3 * L) return 3 + 6 * (t / 3) + 3 * h + (t % 3);
+  if (t == 3 * L) return h ? 2 : 0;
+  if (t == 3 * L + 1) return h ? -1 : 1;
+  return -1;
+}
+__host__ __device__ inline int embed6_col(int k) {
+  int blk, q, h;
+  k_to_bqh(k, blk, q, h);
+  const int t = 16 * blk + q;
+  if (t < 60) return 6 + 12 * (t / 6) + 6 * h + (t % 6);
+  if (t < 63) return (h ? 3 : 0) + (t - 60);
+  return -1;
+}
+
+}  // namespace nsmlp

@@ -1,0 +1,230 @@
+"""Mirror of the render driver / ray-batch operators of nerf_sampling/nerf_pytorch/nerf_utils.py.
+
+Same function names, arguments and returned keys as the reference (render_rays :614-733,
+render_rays_test :736-876, sample_as_in_NeRF :497-611, render / render_test :88-255,
+batchify* :45-85, create_nerf :393-494); the arithmetic runs in HIP kernels.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import ops, run_nerf_helpers
+from .utils import sample_points_around_mean
+
+DEBUG = False
+
+
+def raw2alpha(raw, dists):
+    """nerf_utils.py:27-42 -- kept for API parity (plain tensor expression, not on the hot path)."""
+    return 1.0 - torch.exp(-torch.relu(raw) * dists)
+
+
+def batchify(fn, chunk):
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i : i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+
+    return ret
+
+
+def _batchify(render_fn, rays_flat, chunk, **kwargs):
+    all_returned = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        returned = render_fn(rays_flat[i : i + chunk], **kwargs)
+        for key in returned:
+            all_returned.setdefault(key, []).append(returned[key])
+    return {key: torch.cat(all_returned[key], 0) for key in all_returned}
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
+    return _batchify(render_rays, rays_flat, chunk, **kwargs)
+
+
+def batchify_rays_test(rays_flat, chunk=1024 * 32, **kwargs):
+    return _batchify(render_rays_test, rays_flat, chunk, **kwargs)
+
+
+def prepare_rays(c2w, c2w_staticcam, use_viewdirs, ndc, H, W, K, near, far, rays):
+    """rays [R,11], rays_o, rays_d, shape -- nerf_utils.py:156-188 (ndc=False only)."""
+    if ndc:
+        raise NotImplementedError("NDC rays (LLFF forward-facing scenes) are out of scope (SURVEY.md section 2)")
+    if c2w_staticcam is not None:
+        raise NotImplementedError("c2w_staticcam is not supported")
+    if c2w is not None:
+        rays_o, rays_d, viewdirs, batch = ops.get_rays(H, W, K, c2w, near=near, far=far, want_batch=True)
+        sh = (H, W, 3)
+        if not use_viewdirs:
+            batch = batch[:, :8].contiguous()
+        return batch, rays_o, rays_d, sh
+    rays_o, rays_d = rays
+    sh = rays_d.shape
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    batch = torch.cat([rays_o, rays_d, near_t, far_t], -1)
+    if use_viewdirs:
+        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+        batch = torch.cat([batch, viewdirs], -1)
+    return batch, rays_o, rays_d, sh
+
+
+def _render(batch_fn, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, **kwargs):
+    rays, rays_o, rays_d, sh = prepare_rays(c2w=c2w, c2w_staticcam=c2w_staticcam, use_viewdirs=use_viewdirs,
+                                            ndc=ndc, H=H, W=W, K=K, near=near, far=far, rays=rays)
+    all_returned = batch_fn(rays, chunk, **kwargs)
+    for key in all_returned:
+        all_returned[key] = torch.reshape(all_returned[key], list(sh[:-1]) + list(all_returned[key].shape[1:]))
+    key_extract = ["depth_net_rgb_map", "depth_net_disp_map"]
+    ret_list = [all_returned[key] for key in key_extract]
+    ret_dict = {key: all_returned[key] for key in all_returned if key not in key_extract}
+    ret_dict["rays_o"], ret_dict["rays_d"] = rays_o, rays_d
+    return ret_list + [ret_dict]
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.0, far=1.0, use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """[rgb, disp, extras] through render_rays (nerf_utils.py:88-153)."""
+    return _render(batchify_rays, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, **kwargs)
+
+
+def render_test(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.0, far=1.0, use_viewdirs=False,
+                c2w_staticcam=None, **kwargs):
+    """[rgb, disp, extras] through render_rays_test (nerf_utils.py:191-255)."""
+    return _render(batchify_rays_test, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam,
+                   **kwargs)
+
+
+def create_nerf(args, model):
+    """(render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer) -- nerf_utils.py:393-494."""
+    embed_fn, input_ch = run_nerf_helpers.get_embedder(args.multires, args.i_embed, args.input_dims_embed)
+    input_ch_views, embeddirs_fn = 0, None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = run_nerf_helpers.get_embedder(args.multires_views, args.i_embed,
+                                                                     args.input_dims_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    dev = "cuda" if args.device == "cuda" else args.device
+    model_nerf = model(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                       input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+    grad_vars = list(model_nerf.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = model(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                           skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(dev)
+        grad_vars += list(model_fine.parameters())
+    network_query_fn = lambda inputs, viewdirs, network_fn: args.run_network(  # noqa: E731
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start = 0
+    ckpts = []
+    if args.ft_path is not None and args.ft_path != "None":
+        ckpts = [args.ft_path]
+    elif os.path.isdir(os.path.join(args.basedir, args.expname)):
+        d = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f]
+    if len(ckpts) > 0 and not args.no_reload:
+        from .utils import load_nerf
+
+        ckpt = torch.load(ckpts[-1], weights_only=True, map_location=dev)
+        start = ckpt["global_step"]
+        load_nerf(model_nerf, model_fine, optimizer, ckpt)
+    render_kwargs_train = {
+        "network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
+        "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model_nerf,
+        "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
+        "trainer": args,
+    }
+    if args.dataset_type != "llff" or getattr(args, "no_ndc", False):
+        render_kwargs_train["ndc"] = False
+        render_kwargs_train["lindisp"] = args.lindisp
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test["perturb"] = False
+    render_kwargs_test["raw_noise_std"] = 0.0
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer
+
+
+def sample_as_in_NeRF(ray_batch, network_fn, network_fine, network_query_fn, N_samples, trainer, perturb,
+                      raw_noise_std, lindisp, white_bkgd, kwargs, pytest):
+    """Vanilla coarse+fine pass; 8-tuple (density, z, pts, rgb_map, weights, alphas, disp, raw) -- :497-611."""
+    N_rays = ray_batch.shape[0]
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
+    near, far = ray_batch[:, 6].contiguous(), ray_batch[:, 7].contiguous()
+    (c_rgb, c_disp, c_acc, c_w, _c_depth, c_z, c_w, _c_raw, _c_alphas) = trainer.sample_coarse_points(
+        near=near, far=far, perturb=perturb, N_rays=N_rays, N_samples=N_samples, viewdirs=viewdirs,
+        network_fn=network_fn, network_query_fn=network_query_fn, rays_o=rays_o, rays_d=rays_d,
+        raw_noise_std=raw_noise_std, white_bkgd=white_bkgd, pytest=pytest, lindisp=lindisp, kwargs=kwargs)
+    (_r0, _d0, _a0, f_rgb, f_disp, _f_acc, f_raw, f_z, f_pts, f_density, f_alphas, f_w) = trainer.sample_fine_points(
+        z_vals=c_z, weights=c_w, perturb=perturb, pytest=pytest, rays_d=rays_d, rays_o=rays_o, rgb_map=c_rgb,
+        disp_map=c_disp, acc_map=c_acc, network_fn=network_fn, network_fine=network_fine,
+        network_query_fn=network_query_fn, viewdirs=viewdirs, raw_noise_std=raw_noise_std, white_bkgd=white_bkgd)
+    return f_density, f_z, f_pts, f_rgb, f_w, f_alphas, f_disp, f_raw
+
+
+def render_rays(ray_batch, network_fn, network_query_fn, N_samples, trainer, retraw=True, lindisp=False,
+                perturb=0.0, N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
+                verbose=False, pytest=False, **kwargs):
+    """Training operator, forward (nerf_utils.py:614-733); same keys / host copies as the reference."""
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
+    (_dens, fine_z, _pts, _rgb, fine_w, _al, _disp, _raw) = sample_as_in_NeRF(
+        ray_batch=ray_batch, N_samples=N_samples, network_fn=network_fn, network_fine=network_fine,
+        network_query_fn=network_query_fn, trainer=trainer, perturb=perturb, raw_noise_std=raw_noise_std,
+        lindisp=lindisp, white_bkgd=white_bkgd, pytest=pytest, kwargs=kwargs)
+    max_z_vals, _, _ = ops.argmax_gather(fine_w, fine_z)
+    max_pts = ops.points_along_rays(rays_o, rays_d, max_z_vals)
+    depth_net_z_vals = kwargs["depth_network"](rays_o, rays_d)
+    depth_net_pts = ops.points_along_rays(rays_o, rays_d, depth_net_z_vals)
+    net = network_fine if network_fine is not None else network_fn
+    depth_net_raw = network_query_fn(depth_net_pts, viewdirs, net)
+    (rgb_map, disp_map, _acc, _depth, _density, _alphas, _weights) = trainer.raw2outputs(
+        raw=depth_net_raw, z_vals=depth_net_z_vals, rays_d=rays_d, raw_noise=raw_noise_std, white_bkdg=white_bkgd,
+        pytest=pytest)  # (sic) misspelled keywords, as in the reference: noise 0, white background
+    ret = {"depth_net_rgb_map": rgb_map, "depth_net_disp_map": disp_map, "depth_net_z_vals": depth_net_z_vals,
+           "max_z_vals": max_z_vals, "depth_net_pts": depth_net_pts.cpu(), "max_pts": max_pts.cpu()}
+    if retraw:
+        ret["raw"] = depth_net_raw.cpu()
+    return ret
+
+
+def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer, retraw=True, lindisp=False,
+                     perturb=0.0, N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
+                     verbose=False, pytest=False, **kwargs):
+    """Inference operator (nerf_utils.py:736-876); same keys, shapes and host copies as the reference."""
+    rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
+    viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
+    ret = {}
+    if trainer.compare_nerf or trainer.use_nerf_max_pts or trainer.use_full_nerf:
+        (_dens, fine_z, fine_pts, fine_rgb, fine_w, _al, fine_disp, fine_raw) = sample_as_in_NeRF(
+            ray_batch=ray_batch, N_samples=N_samples, network_fn=network_fn, network_fine=network_fine,
+            network_query_fn=network_query_fn, trainer=trainer, perturb=perturb, raw_noise_std=raw_noise_std,
+            lindisp=lindisp, white_bkgd=white_bkgd, pytest=pytest, kwargs=kwargs)
+        max_z_vals, max_weights, max_rgb_map = ops.argmax_gather(fine_w, fine_z, fine_raw)
+        max_pts = ops.points_along_rays(rays_o, rays_d, max_z_vals)
+        ret["max_z_vals"], ret["max_pts"], ret["max_weights"] = max_z_vals.cpu(), max_pts.cpu(), max_weights.cpu()
+    if trainer.use_nerf_max_pts:
+        rgb_map, disp_map = max_rgb_map, torch.zeros_like(max_rgb_map)  # [R,3] disp: reference quirk, :826
+        weights, pts, z_vals = max_weights, max_pts, max_z_vals
+    elif trainer.use_full_nerf:
+        rgb_map, disp_map, weights, pts, z_vals = fine_rgb, fine_disp, fine_w, fine_pts, fine_z
+    else:
+        mean = kwargs["depth_network"](rays_o, rays_d)
+        pts, z_vals = sample_points_around_mean(rays_o=rays_o, rays_d=rays_d, mean=mean,
+                                                n_samples=trainer.n_depth_samples, mode=trainer.sampling_mode,
+                                                std=trainer.distance)
+        net = network_fine if network_fine is not None else network_fn
+        raw = network_query_fn(pts, viewdirs, net)
+        (rgb_map, disp_map, _acc, _depth, _density, _alphas, weights) = trainer.raw2outputs(
+            raw=raw, z_vals=z_vals, rays_d=rays_d, raw_noise=raw_noise_std, white_bkdg=white_bkgd, pytest=pytest)
+    ret["depth_net_rgb_map"] = rgb_map
+    ret["depth_net_weights"] = weights.cpu()
+    ret["depth_net_disp_map"] = disp_map.cpu()
+    ret["depth_net_z_vals"] = z_vals.cpu()
+    ret["depth_net_pts"] = pts.cpu()
+    return ret

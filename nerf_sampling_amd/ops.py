@@ -1,0 +1,400 @@
+"""Tensor-level wrappers over the C ABI: torch CUDA (ROCm) tensors in, torch tensors out.
+
+PyTorch is used for device memory and streams only; every arithmetic step runs in
+libnerf_sampling_hip.so.  All inputs must be fp32 device tensors; outputs are freshly allocated on
+the same device.  Calls are asynchronous on torch's current stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+
+_DTYPES = {"f32": _lib.DTYPE_F32, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32,
+           "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16,
+           "f16": _lib.DTYPE_F16, "fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16}
+_MODES = {"depth_only": _lib.MODE_DEPTH_ONLY, "uniform": _lib.MODE_UNIFORM, "gaussian": _lib.MODE_GAUSSIAN}
+
+_compute_dtype = "f32"
+
+
+def set_compute_dtype(name: str) -> None:
+    """MFMA operand precision used when a network is packed without an explicit dtype."""
+    global _compute_dtype
+    if name not in _DTYPES:
+        raise ValueError(f"unknown dtype {name!r}; expected one of {sorted(_DTYPES)}")
+    _compute_dtype = name
+
+
+def get_compute_dtype() -> str:
+    return _compute_dtype
+
+
+def dtype_code(name: Optional[str]) -> int:
+    return _DTYPES[name or _compute_dtype]
+
+
+def _dev(t: Tensor, name: str) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); this path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+# ---- a1 -------------------------------------------------------------------------------------------
+def get_rays(H: int, W: int, K, c2w, row0: int = 0, row1: Optional[int] = None, near: float = 0.0,
+             far: float = 1.0, device=None, want_batch: bool = False):
+    """rays_o, rays_d, viewdirs [R,3] (and ray_batch [R,11]) for image rows [row0,row1)."""
+    lib = _lib.load()
+    row1 = H if row1 is None else row1
+    device = torch.device(device if device is not None else (c2w.device if isinstance(c2w, Tensor) and c2w.is_cuda else "cuda"))
+    c2w_h = (c2w.detach().cpu().numpy() if isinstance(c2w, Tensor) else np.asarray(c2w)).astype(np.float32)[:3, :4]
+    c2w_h = np.ascontiguousarray(c2w_h)
+    R = (row1 - row0) * W
+    o = torch.empty((R, 3), dtype=torch.float32, device=device)
+    d = torch.empty_like(o)
+    v = torch.empty_like(o)
+    b = torch.empty((R, 11), dtype=torch.float32, device=device) if want_batch else None
+    check(lib.ns_get_rays(H, W, float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]),
+                          c2w_h.ctypes.data_as(C.c_void_p), row0, row1, float(near), float(far),
+                          _ptr(o), _ptr(d), _ptr(v), _ptr(b), _stream(device)), "ns_get_rays")
+    return (o, d, v, b) if want_batch else (o, d, v)
+
+
+# ---- a2 -------------------------------------------------------------------------------------------
+def sphere_intersect(o: Tensor, d: Tensor, radius: float) -> Tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    o, d = _dev(o, "origin"), _dev(d, "direction")
+    R = o.shape[0]
+    t = torch.empty((R, 2), dtype=torch.float32, device=o.device)
+    p = torch.empty((R, 2, 3), dtype=torch.float32, device=o.device)
+    check(lib.ns_sphere_intersect(_ptr(o), _ptr(d), R, float(radius), _ptr(t), _ptr(p), _stream(o.device)),
+          "ns_sphere_intersect")
+    return t, p
+
+
+def solve_quadratic(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    lib = _lib.load()
+    a, b, c = _dev(a, "a"), _dev(b, "b"), _dev(c, "c")
+    out = torch.empty((2,) + tuple(a.shape), dtype=torch.float32, device=a.device)
+    check(lib.ns_solve_quadratic(_ptr(a), _ptr(b), _ptr(c), a.numel(), _ptr(out), _stream(a.device)),
+          "ns_solve_quadratic")
+    return out
+
+
+# ---- a3 -------------------------------------------------------------------------------------------
+def posenc(x: Tensor, n_freqs: int) -> Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    d = x.shape[-1]
+    M = x.numel() // d
+    out = torch.empty(tuple(x.shape[:-1]) + (d * (1 + 2 * n_freqs),), dtype=torch.float32, device=x.device)
+    check(lib.ns_posenc(_ptr(x), M, d, n_freqs, _ptr(out), _stream(x.device)), "ns_posenc")
+    return out
+
+
+# ---- packed networks ------------------------------------------------------------------------------
+class PackedWeights:
+    """Owner of an ns_weights handle (device weight stream)."""
+
+    def __init__(self, handle: int, kind: str, dtype: str, device):
+        self.handle = C.c_void_p(handle)
+        self.kind, self.dtype, self.device = kind, dtype, device
+
+    @property
+    def stream_bytes(self) -> int:
+        return int(_lib.load().ns_weights_stream_bytes(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().ns_weights_destroy(self.handle)
+                self.handle = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def _host_ptr_array(tensors: Sequence[Tensor]):
+    keep = [np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32)) for t in tensors]
+    arr = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+    return arr, keep
+
+
+def pack_nerf(weights: Sequence[Tensor], biases: Sequence[Tensor], D: int, W: int, skip: int,
+              dtype: Optional[str] = None, device="cuda") -> PackedWeights:
+    """weights/biases in the order pts_linears.0..D-1, feature_linear, alpha_linear, views_linears.0, rgb_linear."""
+    lib = _lib.load()
+    wa, k1 = _host_ptr_array(weights)
+    ba, k2 = _host_ptr_array(biases)
+    out = C.c_void_p()
+    name = dtype or _compute_dtype
+    with torch.cuda.device(device):
+        check(lib.ns_pack_nerf(D, W, skip, wa, ba, dtype_code(name), C.byref(out)), "ns_pack_nerf")
+    return PackedWeights(out.value, "nerf", name, torch.device(device))
+
+
+def pack_depthnet(weights: Sequence[Tensor], biases: Sequence[Tensor], n_layers: int, width: int,
+                  dtype: Optional[str] = None, device="cuda") -> PackedWeights:
+    """order: origin_layers.*, direction_layers.*, intersection_layers.*, cat_layers.{0,2,..}, to_depth.0"""
+    lib = _lib.load()
+    wa, k1 = _host_ptr_array(weights)
+    ba, k2 = _host_ptr_array(biases)
+    out = C.c_void_p()
+    name = dtype or _compute_dtype
+    with torch.cuda.device(device):
+        check(lib.ns_pack_depthnet(n_layers, width, wa, ba, dtype_code(name), C.byref(out)), "ns_pack_depthnet")
+    return PackedWeights(out.value, "depthnet", name, torch.device(device))
+
+
+# ---- a4 -------------------------------------------------------------------------------------------
+def depthnet_forward(net: PackedWeights, o: Tensor, d: Tensor, near: float = 2.0, far: float = 6.0,
+                     sphere_radius: float = 2.0) -> Tensor:
+    lib = _lib.load()
+    o, d = _dev(o, "rays_o"), _dev(d, "rays_d")
+    R = o.shape[0]
+    z = torch.empty((R, 1), dtype=torch.float32, device=o.device)
+    check(lib.ns_depthnet_forward(net.handle, _ptr(o), _ptr(d), R, float(near), float(far), float(sphere_radius),
+                                  _ptr(z), _stream(o.device)), "ns_depthnet_forward")
+    return z
+
+
+# ---- a5 -------------------------------------------------------------------------------------------
+def place_samples(o: Tensor, d: Tensor, mean: Tensor, n_samples: int, mode: str, std: float,
+                  noise: Optional[Tensor] = None, want_pts: bool = True):
+    lib = _lib.load()
+    if mode not in _MODES:
+        raise ValueError(f"unknown sampling mode {mode!r}")
+    o, d, mean = _dev(o, "rays_o"), _dev(d, "rays_d"), _dev(mean, "mean")
+    R = o.shape[0]
+    N = 1 if mode == "depth_only" else int(n_samples)
+    if mode == "gaussian" and noise is None:
+        # same draw shape / order as the reference's torch.randn(mean.shape[0], n_samples - 1)
+        noise = torch.randn(R, N - 1, device=o.device)
+    if noise is not None:
+        noise = _dev(noise, "noise")
+    z = torch.empty((R, N), dtype=torch.float32, device=o.device)
+    pts = torch.empty((R, N, 3), dtype=torch.float32, device=o.device) if want_pts else None
+    check(lib.ns_place_samples(_MODES[mode], _ptr(o), _ptr(d), _ptr(mean), _ptr(noise), R, N, float(std),
+                               _ptr(pts), _ptr(z), _stream(o.device)), "ns_place_samples")
+    return pts, z
+
+
+def points_along_rays(o: Tensor, d: Tensor, z: Tensor) -> Tensor:
+    lib = _lib.load()
+    o, d, z = _dev(o, "rays_o"), _dev(d, "rays_d"), _dev(z, "z")
+    R, N = z.shape
+    pts = torch.empty((R, N, 3), dtype=torch.float32, device=o.device)
+    check(lib.ns_points_along_rays(_ptr(o), _ptr(d), _ptr(z), R, N, _ptr(pts), _stream(o.device)),
+          "ns_points_along_rays")
+    return pts
+
+
+# ---- a6 / a7 ----------------------------------------------------------------------------------------
+def nerf_forward(net: PackedWeights, pts: Tensor, viewdirs: Tensor) -> Tensor:
+    """pts [R,N,3], viewdirs [R,3] -> raw [R,N,4]"""
+    lib = _lib.load()
+    pts, viewdirs = _dev(pts, "pts"), _dev(viewdirs, "viewdirs")
+    R, N = pts.shape[0], pts.shape[1]
+    raw = torch.empty((R, N, 4), dtype=torch.float32, device=pts.device)
+    check(lib.ns_nerf_forward(net.handle, _ptr(pts), None, None, None, _ptr(viewdirs), R, N, _ptr(raw),
+                              _stream(pts.device)), "ns_nerf_forward")
+    return raw
+
+
+def nerf_forward_rays(net: PackedWeights, o: Tensor, d: Tensor, z: Tensor, viewdirs: Tensor) -> Tensor:
+    """points formed in-kernel as o + d*z; z [R,N] -> raw [R,N,4]"""
+    lib = _lib.load()
+    o, d, z, viewdirs = _dev(o, "rays_o"), _dev(d, "rays_d"), _dev(z, "z"), _dev(viewdirs, "viewdirs")
+    R, N = z.shape
+    raw = torch.empty((R, N, 4), dtype=torch.float32, device=z.device)
+    check(lib.ns_nerf_forward(net.handle, None, _ptr(o), _ptr(d), _ptr(z), _ptr(viewdirs), R, N, _ptr(raw),
+                              _stream(z.device)), "ns_nerf_forward")
+    return raw
+
+
+def nerf_forward_embedded(net: PackedWeights, x: Tensor) -> Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    if x.shape[-1] != 90:
+        raise NotImplementedError(f"embedded input must be 63+27=90 wide, got {x.shape[-1]}")
+    M = x.numel() // 90
+    raw = torch.empty(tuple(x.shape[:-1]) + (4,), dtype=torch.float32, device=x.device)
+    check(lib.ns_nerf_forward_embedded(net.handle, _ptr(x), M, _ptr(raw), _stream(x.device)),
+          "ns_nerf_forward_embedded")
+    return raw
+
+
+# ---- a8 -------------------------------------------------------------------------------------------
+def raw2outputs(raw: Tensor, z: Tensor, rays_d: Tensor, noise: Optional[Tensor] = None,
+                white_bkgd: bool = True, want_per_sample: bool = True):
+    """-> rgb [R,3], disp [R], acc [R], depth [R], alphas [R,N] | None, weights [R,N] | None"""
+    lib = _lib.load()
+    raw, z, rays_d = _dev(raw, "raw"), _dev(z, "z_vals"), _dev(rays_d, "rays_d")
+    R, N = z.shape
+    dev = raw.device
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((R,), dtype=torch.float32, device=dev)
+    acc = torch.empty_like(disp)
+    depth = torch.empty_like(disp)
+    alphas = torch.empty((R, N), dtype=torch.float32, device=dev) if want_per_sample else None
+    weights = torch.empty((R, N), dtype=torch.float32, device=dev) if want_per_sample else None
+    if noise is not None:
+        noise = _dev(noise, "noise")
+    check(lib.ns_raw2outputs(_ptr(raw), _ptr(z), _ptr(rays_d), _ptr(noise), R, N, int(bool(white_bkgd)),
+                             _ptr(rgb), _ptr(disp), _ptr(acc), _ptr(depth), _ptr(alphas), _ptr(weights),
+                             _stream(dev)), "ns_raw2outputs")
+    return rgb, disp, acc, depth, alphas, weights
+
+
+# ---- a11 ------------------------------------------------------------------------------------------
+def coarse_z(near: Tensor, far: Tensor, n_samples: int, lindisp: bool, t_rand: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    near, far = _dev(near.reshape(-1), "near"), _dev(far.reshape(-1), "far")
+    R = near.shape[0]
+    if t_rand is not None:
+        t_rand = _dev(t_rand, "t_rand")
+    z = torch.empty((R, n_samples), dtype=torch.float32, device=near.device)
+    check(lib.ns_coarse_z(_ptr(near), _ptr(far), R, n_samples, int(bool(lindisp)), _ptr(t_rand), _ptr(z),
+                          _stream(near.device)), "ns_coarse_z")
+    return z
+
+
+def sample_pdf(bins: Tensor, weights: Tensor, n_samples: int, u: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    bins, weights = _dev(bins, "bins"), _dev(weights, "weights")
+    R, Nb = bins.shape
+    if weights.shape[-1] != Nb - 1:
+        raise ValueError("weights must have one element fewer than bins")
+    if u is not None:
+        u = _dev(u, "u")
+    out = torch.empty((R, n_samples), dtype=torch.float32, device=bins.device)
+    check(lib.ns_sample_pdf(_ptr(bins), _ptr(weights), R, Nb, n_samples, _ptr(u), _ptr(out), _stream(bins.device)),
+          "ns_sample_pdf")
+    return out
+
+
+def importance_z(z: Tensor, weights: Tensor, n_importance: int, u: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    z, weights = _dev(z, "z_vals"), _dev(weights, "weights")
+    R, Nc = z.shape
+    if u is not None:
+        u = _dev(u, "u")
+    out = torch.empty((R, Nc + n_importance), dtype=torch.float32, device=z.device)
+    check(lib.ns_importance_z(_ptr(z), _ptr(weights), R, Nc, n_importance, _ptr(u), _ptr(out), _stream(z.device)),
+          "ns_importance_z")
+    return out
+
+
+def sort_rows(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    x = _dev(x, "x")
+    R, N = x.shape
+    out = torch.empty_like(x)
+    check(lib.ns_sort_rows(_ptr(x), R, N, _ptr(out), _stream(x.device)), "ns_sort_rows")
+    return out
+
+
+def argmax_gather(weights: Tensor, z: Tensor, raw: Optional[Tensor] = None):
+    lib = _lib.load()
+    weights, z = _dev(weights, "weights"), _dev(z, "z_vals")
+    R, N = weights.shape
+    dev = weights.device
+    max_z = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    max_w = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    max_rgb = None
+    if raw is not None:
+        raw = _dev(raw, "raw")
+        max_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    check(lib.ns_argmax_gather(_ptr(weights), _ptr(z), _ptr(raw), R, N, _ptr(max_z), _ptr(max_w), _ptr(max_rgb),
+                               _stream(dev)), "ns_argmax_gather")
+    return max_z, max_w, max_rgb
+
+
+# ---- a9 fused -------------------------------------------------------------------------------------
+class RenderWorkspace:
+    """Reusable device workspace for render_rays_depthnet (grown on demand, never shrunk)."""
+
+    def __init__(self):
+        self.buf: Optional[Tensor] = None
+
+    def get(self, nbytes: int, device) -> Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+_default_ws = RenderWorkspace()
+
+
+def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=None, camera=None,
+                         n_samples: int, mode: str, std: float, noise: Optional[Tensor] = None,
+                         near: float = 2.0, far: float = 6.0, sphere_radius: float = 2.0,
+                         white_bkgd: bool = True, extras: bool = False, workspace: Optional[RenderWorkspace] = None,
+                         device="cuda"):
+    """DepthNet -> placement -> NeRF MLP -> compositing as one C call.
+
+    rays = (o, d, viewdirs) device tensors, or camera = (H, W, K, c2w, row0, row1) to generate
+    the rays on the device.  Returns dict(rgb [R,3], disp [R], and with extras z/weights/pts).
+    """
+    lib = _lib.load()
+    a = _lib.RenderArgs()
+    a.depthnet, a.nerf = depthnet.handle, nerf.handle
+    keep = []
+    if rays is not None:
+        o, d, v = (_dev(t, n) for t, n in zip(rays, ("rays_o", "rays_d", "viewdirs")))
+        keep += [o, d, v]
+        device = o.device
+        R = o.shape[0]
+        a.o_dev, a.d_dev, a.viewdirs_dev, a.R = o.data_ptr(), d.data_ptr(), v.data_ptr(), R
+    else:
+        H, W, K, c2w, row0, row1 = camera
+        c2w_h = (c2w.detach().cpu().numpy() if isinstance(c2w, Tensor) else np.asarray(c2w)).astype(np.float32)[:3, :4]
+        a.H, a.W, a.row0, a.row1 = H, W, row0, row1
+        a.fx, a.fy, a.cx, a.cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+        for i, val in enumerate(c2w_h.reshape(-1)):
+            a.c2w[i] = float(val)
+        R = (row1 - row0) * W
+        a.R = R
+    device = torch.device(device)
+    N = 1 if mode == "depth_only" else int(n_samples)
+    a.mode, a.N, a.std_ = _MODES[mode], N, float(std)
+    if mode == "gaussian":
+        if noise is None:
+            noise = torch.randn(R, N - 1, device=device)
+        noise = _dev(noise, "noise")
+        keep.append(noise)
+        a.noise_dev = noise.data_ptr()
+    a.near_, a.far_, a.sphere_radius, a.white_bkgd = float(near), float(far), float(sphere_radius), int(bool(white_bkgd))
+    nbytes = int(lib.ns_render_workspace_bytes(R, N))
+    ws = (workspace or _default_ws).get(nbytes, device)
+    base = ws.data_ptr()
+    a.workspace_dev = (base + 255) & ~255
+    out = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=device),
+           "disp": torch.empty((R,), dtype=torch.float32, device=device)}
+    a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
+    if extras:
+        out["z"] = torch.empty((R, N), dtype=torch.float32, device=device)
+        out["weights"] = torch.empty((R, N), dtype=torch.float32, device=device)
+        out["pts"] = torch.empty((R, N, 3), dtype=torch.float32, device=device)
+        a.z_dev, a.weights_dev, a.pts_dev = out["z"].data_ptr(), out["weights"].data_ptr(), out["pts"].data_ptr()
+    check(lib.ns_render_rays_depthnet(C.byref(a), _stream(device)), "ns_render_rays_depthnet")
+    return out

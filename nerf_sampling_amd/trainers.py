@@ -1,0 +1,199 @@
+"""Mirror of the trainer-side operators the render path calls back into.
+
+Reference: nerf_sampling/nerf_pytorch/trainers/Trainer.py (run_network :789-806,
+sample_coarse_points :579-649, sample_fine_points :651-710, _sample_points :553-577),
+trainers/Blender.py, nerf_sampling/trainers/sampling_trainer.py (DepthNetTrainer.raw2outputs
+:153-230, create_nerf_model :54-122).  Dataset I/O, logging and the optimisation loop are out
+of scope; ``train`` says so loudly.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import nerf_utils, ops, utils
+from .depth_net import DepthNet
+from .run_nerf_helpers import Embedder, NeRF
+
+
+class Trainer:
+    """Attribute bag with the reference's constructor arguments and defaults (Trainer.py:19-130)."""
+
+    def __init__(self, dataset_type, basedir, expname, no_batching, datadir, device="cpu", render_test=False,
+                 config_path=None, N_rand=32 * 32 * 4, render_only=False, chunk=1024 * 32, render_factor=0,
+                 multires=10, i_embed=0, multires_views=4, netchunk=1024 * 64, lrate=5e-4, lrate_decay=250,
+                 use_viewdirs=True, N_importance=0, netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256,
+                 ft_path=None, perturb=1.0, raw_noise_std=0.0, N_samples=64, lindisp=True, precrop_iters=0,
+                 precrop_frac=0.5, i_weights=10000, i_testset=100, i_video=5000, i_print=100,
+                 input_dims_embed: int = 1, save_train_set_render: bool = True, depth_net_lr: float = 0.0001,
+                 train_depth_net_only: bool = False, trial=None, single_image=False, single_ray=False,
+                 save_scene_data=False, compare_nerf=False, use_nerf_max_pts=False, use_full_nerf=False):
+        for k, v in list(locals().items()):
+            if k != "self":
+                setattr(self, k, v)
+        self.use_batching = not no_batching
+        self.no_reload = False
+        self.start = None
+        self.K = self.global_step = self.W = self.H = self.c2w = None
+
+    def cast_intrinsics_to_right_types(self, hwf):
+        H, W, focal = hwf
+        H, W = int(H), int(W)
+        if self.K is None:
+            self.K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]])
+        self.H, self.W = H, W
+        return [H, W, focal]
+
+    # ---- operators called from render_rays / render_rays_test ------------------------------------
+    def run_network(self, inputs, viewdirs, fn, embed_fn, embeddirs_fn, netchunk=1024 * 64):
+        """Embed + MLP: inputs [R,N,3], viewdirs [R,3] -> [R,N,4]  (Trainer.py:789-806).
+
+        With this package's NeRF module and 10/4-frequency embedders the whole operator is one
+        MFMA kernel (no [R*N,90] embedding in memory, no netchunk loop).
+        """
+        fused = (isinstance(fn, NeRF) and isinstance(embed_fn, Embedder) and isinstance(embeddirs_fn, Embedder)
+                 and viewdirs is not None and embed_fn.num_freqs == 10 and embeddirs_fn.num_freqs == 4
+                 and embed_fn.input_dims == 3 and embeddirs_fn.input_dims == 3)
+        if fused:
+            return ops.nerf_forward(fn.packed(), inputs, viewdirs)
+        inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        embedded = embed_fn(inputs_flat)
+        if viewdirs is not None:
+            input_dirs = viewdirs[:, None].expand(inputs.shape)
+            embedded = torch.cat([embedded, embeddirs_fn(torch.reshape(input_dirs, [-1, input_dirs.shape[-1]]))], -1)
+        outputs_flat = nerf_utils.batchify(fn, netchunk)(embedded)
+        return torch.reshape(outputs_flat, list(inputs.shape[:-1]) + [outputs_flat.shape[-1]])
+
+    def _sample_points(self, z_vals_mid, weights, perturb, pytest, rays_d, rays_o, n_importance=None):
+        from .run_nerf_helpers import sample_pdf
+
+        if n_importance is None:
+            n_importance = self.N_importance
+        z_samples = sample_pdf(z_vals_mid, weights[..., 1:-1], n_importance, det=(perturb == 0.0), pytest=pytest)
+        z_samples = z_samples.detach()
+        return z_samples, ops.points_along_rays(rays_o, rays_d, z_samples)
+
+    def sample_coarse_points(self, near, far, perturb, N_rays, N_samples, viewdirs, network_fn, network_query_fn,
+                             rays_o, rays_d, raw_noise_std, white_bkgd, pytest, lindisp, **kwargs):
+        """9-tuple in the reference's order (Trainer.py:579-649)."""
+        rgb_map = disp_map = acc_map = depth_map = alphas_map = raw = weights = z_vals = None
+        if N_samples > 0:
+            t_rand = None
+            if perturb > 0.0:
+                if pytest:
+                    np.random.seed(0)
+                    t_rand = torch.tensor(np.random.rand(N_rays, N_samples), dtype=torch.float32, device=rays_o.device)
+                else:
+                    t_rand = torch.rand([N_rays, N_samples], device=rays_o.device)
+            z_vals = ops.coarse_z(near, far, N_samples, lindisp, t_rand)
+            pts = ops.points_along_rays(rays_o, rays_d, z_vals)
+            raw = network_query_fn(pts, viewdirs, network_fn)
+            rgb_map, disp_map, acc_map, depth_map, density, alphas, weights = self.raw2outputs(
+                raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
+        return rgb_map, disp_map, acc_map, weights, depth_map, z_vals, weights, raw, alphas_map
+
+    def sample_fine_points(self, z_vals, weights, perturb, pytest, rays_d, rays_o, rgb_map, disp_map, acc_map,
+                           network_fn, network_fine, network_query_fn, viewdirs, raw_noise_std, white_bkgd):
+        """12-tuple in the reference's order (Trainer.py:651-710)."""
+        rgb_map_0 = disp_map_0 = acc_map_0 = raw = None
+        pts = density = alphas = None
+        if self.N_importance > 0:
+            rgb_map_0, disp_map_0, acc_map_0 = rgb_map, disp_map, acc_map
+            u = None
+            if perturb != 0.0:
+                if pytest:
+                    np.random.seed(0)
+                    u = torch.tensor(np.random.rand(z_vals.shape[0], self.N_importance), dtype=torch.float32,
+                                     device=z_vals.device)
+                else:
+                    u = torch.rand([z_vals.shape[0], self.N_importance], device=z_vals.device)
+            # z_mid, sample_pdf(weights[1:-1]) and sort(cat[z, samples]) in one kernel
+            z_vals = ops.importance_z(z_vals, weights, self.N_importance, u)
+            pts = ops.points_along_rays(rays_o, rays_d, z_vals)
+            run_fn = network_fn if network_fine is None else network_fine
+            raw = network_query_fn(pts, viewdirs, run_fn)
+            rgb_map, disp_map, acc_map, depth_map, density, alphas, weights = self.raw2outputs(
+                raw, z_vals, rays_d, raw_noise_std, white_bkgd, pytest=pytest)
+        return (rgb_map_0, disp_map_0, acc_map_0, rgb_map, disp_map, acc_map, raw, z_vals, pts, density, alphas,
+                weights)
+
+    def train(self, N_iters=200000 + 1):
+        raise NotImplementedError(
+            "nerf_sampling_amd accelerates the render hot path only; dataset loading, render_path and the "
+            "optimisation loop of the reference are out of scope this round (SURVEY.md section 8f).")
+
+
+class BlenderTrainer(Trainer):
+    def __init__(self, half_res, white_bkgd, testskip=8, near=2.0, far=6.0, **kwargs):
+        self.half_res, self.testskip, self.white_bkgd = half_res, testskip, white_bkgd
+        self.near, self.far = near, far
+        super().__init__(**kwargs)
+
+
+class DepthNetTrainer(BlenderTrainer):
+    """Constructor and operator signatures of sampling_trainer.py:17-52,153-230."""
+
+    def __init__(self, distance=None, sampling_mode=None, n_depth_samples=None,
+                 depth_net_path: Optional[str] = None, n_layers: int = 6, layer_width: int = 256,
+                 sphere_radius: float = 2.0, **kwargs):
+        self.n_layers, self.layer_width = n_layers, layer_width
+        self.depth_net_path, self.sphere_radius = depth_net_path, sphere_radius
+        self.distance, self.n_depth_samples, self.sampling_mode = distance, n_depth_samples, sampling_mode
+        super().__init__(**kwargs)
+
+    def create_nerf_model(self):
+        """(optimizer, sampling_optimizer, render_kwargs_train, render_kwargs_test) -- sampling_trainer.py:54-122.
+
+        Checkpoints in the reference's .tar format are read with torch.load(weights_only=True).
+        """
+        render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer = nerf_utils.create_nerf(self, NeRF)
+        bds = {"near": self.near, "far": self.far}
+        render_kwargs_train.update(bds)
+        render_kwargs_test.update(bds)
+        sizes = [self.layer_width for _ in range(self.n_layers)]
+        dev = "cuda" if self.device == "cuda" else self.device
+        depth_network = DepthNet(hidden_sizes=sizes, cat_hidden_sizes=list(sizes), sphere_radius=self.sphere_radius).to(dev)
+        sampling_optimizer = torch.optim.Adam(params=list(depth_network.parameters()), lr=self.depth_net_lr)
+        ckpts = []
+        if self.depth_net_path is not None and self.depth_net_path != "None":
+            ckpts = [self.depth_net_path]
+        elif os.path.isdir(os.path.join(self.basedir, self.expname)):
+            d = os.path.join(self.basedir, self.expname)
+            ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f]
+        start = None
+        if len(ckpts) > 0 and not self.no_reload:
+            ckpt = torch.load(ckpts[-1], weights_only=True, map_location=dev)
+            start = ckpt["global_step"]
+            utils.load_depth_network(depth_network, sampling_optimizer, ckpt)
+        self.global_step = self.start = start if start is not None else 0
+        for kw, mode in ((render_kwargs_train, "train"), (render_kwargs_test, "test")):
+            kw["depth_network"] = depth_network
+            kw["model_mode"] = mode
+        return optimizer, sampling_optimizer, render_kwargs_train, render_kwargs_test
+
+    def raw2outputs(self, raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=True, pytest=False, **kwargs):
+        """7-tuple (rgb_map, disp_map, acc_map, depth_map, density, alphas, weights).
+
+        Unknown keyword arguments are swallowed exactly like the reference does (its DepthNet-path
+        callers pass the misspelled raw_noise= / white_bkdg=, nerf_utils.py:712-713,862-863).
+        """
+        noise = None
+        if raw_noise_std > 0.0:
+            if pytest:
+                np.random.seed(0)
+                noise = torch.tensor(np.random.rand(*list(raw[..., 3].shape)) * raw_noise_std, dtype=torch.float32,
+                                     device=raw.device)
+            else:
+                noise = torch.randn(raw[..., 3].shape, device=raw.device) * raw_noise_std
+        density = raw[..., 3]
+        if z_vals.shape[-1] == 0:  # sampling_trainer.py:219-220
+            R = raw.shape[0]
+            zeros = torch.zeros((R,), device=raw.device)
+            return (torch.zeros((R, 3), device=raw.device), torch.full((R,), 1e10, device=raw.device), zeros,
+                    zeros.clone(), density, raw[..., 3].clone(), raw[..., 3].clone())
+        rgb_map, disp_map, acc_map, depth_map, alphas, weights = ops.raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
+        return rgb_map, disp_map, acc_map, depth_map, density, alphas, weights

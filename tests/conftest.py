@@ -41,3 +41,38 @@ def scenes():
         return cache[name]
 
     return get
+
+
+def _make_modules(scene_name):
+    """This package's NeRF / DepthNet modules holding the oracle's seeded synthetic weights."""
+    import torch
+
+    from nerf_sampling_amd.depth_net import DepthNet
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+    from oracle import nerf_oracle as O
+
+    cfg, params = O.SCENES[scene_name], O.make_scene(scene_name)
+    out = {}
+    for which in ("coarse", "fine"):
+        net = NeRF(D=cfg[which]["D"], W=cfg[which]["W"], input_ch=63, input_ch_views=27, output_ch=5,
+                   skips=[4], use_viewdirs=True)
+        net.load_state_dict(params[which])
+        out[which] = net.to("cuda")
+    dn = DepthNet(hidden_sizes=[cfg["depth"]["width"]] * cfg["depth"]["n_layers"],
+                  cat_hidden_sizes=[cfg["depth"]["width"]] * cfg["depth"]["n_layers"], sphere_radius=2.0)
+    dn.load_state_dict(params["depth"])
+    out["depth"] = dn.to("cuda")
+    out["params"] = params
+    return out
+
+
+@pytest.fixture(scope="session")
+def gpu_modules():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = _make_modules(name)
+        return cache[name]
+
+    return get

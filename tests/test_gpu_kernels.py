@@ -1,0 +1,314 @@
+"""GPU parity tests, kernel level: every C-ABI entry point against the golden vectors captured from
+the reference and against the CPU oracle on the same seeded inputs (run with -m gpu on an MI355X).
+
+Tolerances are stated per check.  fp32 paths are held to ~1e-6..1e-5 (different summation order /
+libm only); the bf16/fp16 MFMA paths are held to operand-rounding-sized errors.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+def dev(x):
+    return (T(x) if isinstance(x, np.ndarray) else x).float().cuda()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, msg=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True, err_msg=msg)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nerf_sampling_amd import ops as _ops
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+# ---- a1 -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["64", "5x7"])
+def test_get_rays(ops, golden, tag):
+    g = golden(f"rays_{tag}")
+    H, W = int(g["H"]), int(g["W"])
+    o, d, v, b = ops.get_rays(H, W, g["K"], g["c2w"], near=2.0, far=6.0, want_batch=True)
+    close(b, g["ray_batch"], 2e-6, 1e-7)       # fp32 mul/add in the reference's order; norm differs by <= 1 ulp
+    close(o, g["ray_batch"][:, 0:3], 0, 0)
+    close(d, g["ray_batch"][:, 3:6], 2e-6, 1e-7)
+    # row sharding: rows [r0, r1) equal the same rows of the full frame (bit exact)
+    r0, r1 = 1, min(H, 4)
+    o2, d2, v2 = ops.get_rays(H, W, g["K"], g["c2w"], row0=r0, row1=r1)
+    assert torch.equal(d2, d[r0 * W : r1 * W]) and torch.equal(v2, v[r0 * W : r1 * W])
+
+
+def test_get_rays_empty(ops, golden):
+    g = golden("rays_5x7")
+    o, d, v = ops.get_rays(5, 7, g["K"], g["c2w"], row0=2, row1=2)
+    assert o.shape == (0, 3)
+
+
+# ---- a2 -------------------------------------------------------------------------------------------
+def test_sphere(ops, golden):
+    g = golden("sphere")
+    t, p = ops.sphere_intersect(dev(g["known_o"]), dev(g["known_d"]), 1.0)
+    close(t, g["known_t"], 1e-6, 1e-6)
+    close(p, g["known_p"], 1e-6, 1e-6)
+    t, p = ops.sphere_intersect(dev(g["o"]), dev(g["d"]), 2.0)
+    assert np.isnan(g["t"]).sum() == np.isnan(t.cpu().numpy()).sum()
+    close(t, g["t"], 2e-5, 2e-6)   # the discriminant cancels: b^2 - 4ac with fused vs unfused products
+    close(p, g["p"], 2e-5, 2e-5)
+    q = ops.solve_quadratic(dev(g["qa"]), dev(g["qb"]), dev(g["qc"]))
+    close(q, g["qs"], 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize(
+    "o,d,expected",
+    [  # the reference's own known answers, tests.py:250-331, sphere radius 1
+        ([-3.0, 0, 0], [1.0, 0, 0], [[-1.0, 0, 0], [1.0, 0, 0]]),
+        ([-3.0, 0, 0], [0.0, 2, 0], [[float("nan")] * 3] * 2),
+        ([-3.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+        ([-3.0, 1, 0], [1.0, 0, 0], [[0.0, 1, 0], [0.0, 1, 0]]),
+        ([1.0, 0, 0], [0.0, 1, 0], [[1.0, 0, 0], [1.0, 0, 0]]),
+        ([0.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+        ([1.0, 0, 0], [-1.0, 0, 0], [[1.0, 0, 0], [-1.0, 0, 0]]),
+    ],
+)
+def test_sphere_known_answers(ops, o, d, expected):
+    from nerf_sampling_amd.utils import find_intersection_points_with_sphere
+
+    t, p = find_intersection_points_with_sphere(torch.tensor([o]).cuda(), torch.tensor([d]).cuda(),
+                                                torch.tensor([1.0]))
+    assert p.shape == (1, 2, 3)
+    close(p[0], np.array(expected), 1e-6, 1e-6)
+
+
+def test_quadratic_known_answers(ops):
+    from nerf_sampling_amd.utils import solve_quadratic_equation
+
+    nan = float("nan")
+    a = torch.tensor([[1.0, 4, 5], [1, 4, 5]]).cuda(); b = torch.tensor([[1.0, 4, 6], [1, 4, 6]]).cuda()
+    out = solve_quadratic_equation(a, b, torch.ones(2, 3).cuda())
+    close(out, np.array([[[nan, -0.5, -1], [nan, -0.5, -1]], [[nan, -0.5, -0.2], [nan, -0.5, -0.2]]]))
+
+
+# ---- a3 -------------------------------------------------------------------------------------------
+def test_posenc(ops, golden):
+    g = golden("posenc")
+    close(ops.posenc(dev(g["x3"]), 10), g["e63"], 0, 2e-6)     # |arg| up to 3072 rad; libm vs sleef <= 2 ulp
+    close(ops.posenc(dev(g["x3"]) / 6.0, 4), g["e27"], 0, 1e-6)
+    close(ops.posenc(dev(g["x6"]), 10), g["e126"], 0, 2e-6)
+
+
+# ---- a5 -------------------------------------------------------------------------------------------
+def test_place_samples(ops, golden):
+    g = golden("place_samples")
+    o, d, mean = dev(g["o"]), dev(g["d"]), dev(g["mean"]).reshape(-1)
+    for n_s in (2, 3, 32, 64):
+        for std in (0.01, 0.1):
+            pts, z = ops.place_samples(o, d, mean, n_s, "uniform", std)
+            close(z, g[f"uniform_n{n_s}_s{std}_z"], 1e-6, 1e-6)
+            if n_s <= 3:
+                close(pts, g[f"uniform_n{n_s}_s{std}_pts"], 1e-6, 2e-6)
+    pts, z = ops.place_samples(o, d, mean, 32, "depth_only", 0.1)
+    assert z.shape == (256, 1)
+    close(z, g["depth_only_z"], 0, 0)
+    close(pts, g["depth_only_pts"], 1e-6, 1e-6)
+    pts, z = ops.place_samples(o, d, mean, 32, "gaussian", 0.1, noise=dev(g["gaussian_noise"]))
+    close(z, g["gaussian_n32_z"], 1e-6, 1e-6)
+    close(pts[:8], g["gaussian_n32_pts_first8"], 1e-6, 2e-6)
+    assert (z[:, 1:] >= z[:, :-1]).all()
+    # NaN mean (ray missed the sphere) stays NaN in every mode
+    nan_mean = torch.full((4,), float("nan")).cuda()
+    for mode in ("uniform", "gaussian", "depth_only"):
+        _, zz = ops.place_samples(o[:4], d[:4], nan_mean, 8, mode, 0.1)
+        assert torch.isnan(zz).all()
+
+
+# ---- a8 -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1, 2, 32, 64, 192])
+@pytest.mark.parametrize("wb", [True, False])
+def test_raw2outputs(ops, golden, N, wb):
+    g = golden("raw2outputs")
+    rgb, disp, acc, depth, alphas, weights = ops.raw2outputs(dev(g[f"N{N}_raw"]), dev(g[f"N{N}_z"]),
+                                                             dev(g[f"N{N}_rays_d"]), None, wb)
+    p = f"N{N}_wb{int(wb)}_"
+    close(alphas, g[p + "alphas"], 2e-6, 1e-7)
+    close(weights, g[p + "weights"], 3e-5, 1e-7)   # scan vs sequential cumprod: <= N ulp
+    close(acc, g[p + "acc"], 1e-5, 1e-6)
+    close(rgb, g[p + "rgb"], 1e-5, 2e-6)
+    close(depth, g[p + "depth"], 1e-5, 2e-6)
+    close(disp, g[p + "disp"], 2e-5, 1e-6)
+
+
+def test_raw2outputs_noise_and_trainer_signature(ops, golden):
+    from nerf_sampling_amd.trainers import DepthNetTrainer
+
+    g = golden("raw2outputs")
+    noise = dev(g["N32_noise"]) * 0.5
+    rgb, _, _, _, _, w = ops.raw2outputs(dev(g["N32_raw"]), dev(g["N32_z"]), dev(g["N32_rays_d"]), noise, True)
+    close(rgb, g["N32_noisy_rgb"], 1e-5, 2e-6)
+    close(w, g["N32_noisy_weights"], 3e-5, 1e-7)
+    tr = DepthNetTrainer(dataset_type="blender", basedir="/tmp", expname="x", no_batching=True, datadir="",
+                         half_res=True, white_bkgd=True)
+    res = tr.raw2outputs(dev(g["N32_raw"]), dev(g["N32_z"]), dev(g["N32_rays_d"]), raw_noise=0.7, white_bkdg=False)
+    assert len(res) == 7                                  # misspelled kwargs are swallowed (reference quirk)
+    close(res[0], g["N32_wb1_rgb"], 1e-5, 2e-6)
+    close(res[4], g["N32_raw"][..., 3], 0, 0)
+
+
+# ---- a11 pieces -----------------------------------------------------------------------------------
+def test_sample_pdf(ops, golden):
+    g = golden("sample_pdf")
+    det = ops.sample_pdf(dev(g["bins"]), dev(g["weights"]), 128, None)
+    rnd = ops.sample_pdf(dev(g["bins"]), dev(g["weights"]), 128, dev(g["u"]))
+    # the inverse CDF is continuous in u except where a bin's mass is below the reference's 1e-5
+    # threshold; allow a handful of such samples to land in the neighbouring bin
+    for mine, exp in ((det, g["det"]), (rnd, g["rnd"])):
+        err = np.abs(mine.cpu().numpy() - exp)
+        assert np.mean(err > 2e-5) < 2e-3, float(np.mean(err > 2e-5))
+        assert np.median(err) < 1e-6
+
+
+def test_sort_rows(ops):
+    gen = torch.Generator().manual_seed(3)
+    for n in (1, 2, 63, 64, 65, 192, 500):
+        x = torch.randn(37, n, generator=gen)
+        close(ops.sort_rows(x.cuda()), torch.sort(x, -1).values, 0, 0)
+    x = torch.tensor([[3.0, float("nan"), 1.0, 2.0]])
+    out = ops.sort_rows(x.cuda()).cpu()
+    assert out[0, :3].tolist() == [1.0, 2.0, 3.0] and torch.isnan(out[0, 3])
+
+
+def test_importance_z_and_coarse_z(ops, golden):
+    g = golden("hierarchical")
+    rb = T(g["ray_batch"])
+    for lindisp in (True, False):
+        z = ops.coarse_z(rb[:, 6].cuda(), rb[:, 7].cuda(), 64, lindisp)
+        exp = O.coarse_z_vals(rb[:, 6:7], rb[:, 7:8], rb.shape[0], 64, lindisp)
+        close(z, exp, 2e-6, 1e-6)
+    z = ops.coarse_z(rb[:, 6].cuda(), rb[:, 7].cuda(), 64, True, dev(g["perturb_t_rand"]))
+    exp = O.coarse_z_vals(rb[:, 6:7], rb[:, 7:8], rb.shape[0], 64, True, 1.0, T(g["perturb_t_rand"]))
+    close(z, exp, 2e-6, 1e-6)
+    # importance_z == sort(cat[z, sample_pdf(z_mid, w[1:-1])]) of the oracle
+    zc = exp
+    w = torch.rand(rb.shape[0], 64, generator=torch.Generator().manual_seed(5)) ** 3
+    z_mid = 0.5 * (zc[..., 1:] + zc[..., :-1])
+    ref = torch.sort(torch.cat([zc, O.sample_pdf(z_mid, w[..., 1:-1], 128, det=True)], -1), -1).values
+    mine = ops.importance_z(zc.cuda(), w.cuda(), 128, None)
+    err = (mine.cpu() - ref).abs().numpy()
+    assert np.mean(err > 2e-5) < 2e-3 and np.median(err) < 1e-6
+    assert (mine[:, 1:] >= mine[:, :-1]).all()
+
+
+def test_argmax_gather(ops):
+    gen = torch.Generator().manual_seed(8)
+    w = torch.rand(50, 192, generator=gen); z = torch.rand(50, 192, generator=gen); raw = torch.randn(50, 192, 4, generator=gen)
+    w[3] = 0.0                       # ties -> first index
+    w[4, 7] = w[4, 100] = 2.0        # duplicated maximum -> first
+    mz, mw, mrgb = ops.argmax_gather(w.cuda(), z.cuda(), raw.cuda())
+    idx = w.argmax(dim=1, keepdim=True)
+    close(mz, torch.gather(z, 1, idx), 0, 0)
+    close(mw, torch.gather(w, 1, idx), 0, 0)
+    close(mrgb, torch.sigmoid(torch.gather(raw[..., :3], 1, idx.unsqueeze(-1).expand(-1, 1, 3)).squeeze(1)), 1e-6, 1e-7)
+
+
+# ---- a6/a7 NeRF MLP --------------------------------------------------------------------------------
+def _mlp_err(ops, gpu_modules, golden, scene, dtype):
+    g = golden("nerf_mlp")
+    m = gpu_modules(scene)
+    out = {}
+    for which in ("coarse", "fine"):
+        raw = ops.nerf_forward(m[which].packed(dtype), dev(g["pts"]), dev(g["viewdirs"]))
+        out[which] = (raw.cpu().numpy(), g[f"raw_{scene}_{which}"])
+    return out
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_nerf_mlp_f32(ops, gpu_modules, golden, scene):
+    """fp32 MFMA path: exact-fp32 products, k-ordered fma chain; only summation order differs from the CPU GEMM."""
+    for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, "f32").items():
+        scale = np.abs(exp).max(axis=(0, 1))             # per output channel (rgb ~ O(1), sigma ~ O(100))
+        err = np.abs(mine - exp).max(axis=(0, 1)) / scale
+        assert (err < 2e-5).all(), (which, err)
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+@pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("f16", 6e-3)])
+def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
+    """16-bit operands, fp32 accumulation: error is operand rounding (2^-9 bf16, 2^-12 fp16) through ~10 layers."""
+    for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, dtype).items():
+        scale = np.abs(exp).max(axis=(0, 1))
+        rms = np.sqrt(((mine - exp) ** 2).mean(axis=(0, 1))) / scale
+        assert (rms < tol).all(), (which, dtype, rms)
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_nerf_forward_embedded_and_rays(ops, gpu_modules, golden, scene):
+    g = golden("nerf_mlp")
+    m = gpu_modules(scene)
+    pts, view = T(g["pts"]), T(g["viewdirs"])
+    x90 = torch.cat([O.posenc(pts.reshape(-1, 3), 10), O.posenc(view[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1)
+    mine = m["fine"](x90.cuda())                          # NeRF.forward on [M,90]
+    exp = g[f"fwd_{scene}_fine"]
+    scale = np.abs(exp).max(axis=0)
+    assert (np.abs(mine.cpu().numpy() - exp).max(axis=0) / scale < 2e-5).all()
+    # points formed in-kernel from (o, d, z) == explicit points
+    o = torch.randn(64, 3); d = torch.randn(64, 3); z = torch.rand(64, 4) * 4 + 2
+    p = o[:, None] + d[:, None] * z[..., None]
+    a = ops.nerf_forward(m["fine"].packed("f32"), p.cuda(), view.cuda())
+    b = ops.nerf_forward_rays(m["fine"].packed("f32"), o.cuda(), d.cuda(), z.cuda(), view.cuda())
+    close(a, b, 1e-4, 1e-4)
+
+
+def test_nerf_mlp_ragged_sizes(ops, gpu_modules):
+    """Tile tails: sample counts that are not multiples of 32 / of a workgroup, and a single sample."""
+    m = gpu_modules("tiny_synth")
+    gen = torch.Generator().manual_seed(11)
+    p = m["params"]["fine"]
+    for R, N in ((1, 1), (3, 5), (33, 31), (257, 9), (700, 64)):
+        pts = (torch.rand(R, N, 3, generator=gen) * 2 - 1) * 3
+        view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+        exp = O.run_network(p, pts, view).numpy()
+        mine = ops.nerf_forward(m["fine"].packed("f32"), pts.cuda(), view.cuda()).cpu().numpy()
+        scale = np.abs(exp).reshape(-1, 4).max(axis=0) + 1e-6
+        assert (np.abs(mine - exp).reshape(-1, 4).max(axis=0) / scale < 3e-5).all(), (R, N)
+
+
+# ---- a4 DepthNet ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_depthnet_f32(ops, gpu_modules, golden, scene):
+    g = golden("depthnet")
+    z = gpu_modules(scene)["depth"](dev(g["o"]), dev(g["d"]))   # DepthNet.forward -> [R,1]
+    exp = g[f"z_{scene}"]
+    assert z.shape == exp.shape
+    assert torch.isnan(z[256:258]).all()                        # rays that miss the sphere: NaN, as the reference
+    close(z, exp, 0, 2e-4)                                      # z in [2,6]: 2e-4 abs = 5e-5 of the range
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+@pytest.mark.parametrize("dtype,tol", [("bf16", 0.15), ("f16", 0.03)])
+def test_depthnet_16bit(ops, gpu_modules, golden, scene, dtype, tol):
+    g = golden("depthnet")
+    z = ops.depthnet_forward(gpu_modules(scene)["depth"].packed(dtype), dev(g["o"]), dev(g["d"]))
+    exp = g[f"z_{scene}"]
+    ok = ~np.isnan(exp[:, 0])
+    err = np.abs(z.cpu().numpy() - exp)[ok]
+    assert np.sqrt((err ** 2).mean()) < tol, float(np.sqrt((err ** 2).mean()))
+
+
+def test_depthnet_ragged_sizes(ops, gpu_modules):
+    m = gpu_modules("tiny_synth")
+    gen = torch.Generator().manual_seed(12)
+    for R in (1, 31, 33, 300):
+        o = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1) * 4.0
+        d = -o / 4.0 + 0.1 * torch.randn(R, 3, generator=gen)
+        exp = O.depthnet_forward(m["params"]["depth"], o, d)
+        close(m["depth"](o.cuda(), d.cuda()), exp, 0, 2e-4)
