@@ -110,7 +110,9 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
 /* ---- a8  raw2alpha + DepthNetTrainer.raw2outputs (nerf_utils.py:27-42, sampling_trainer.py
  * :153-230).  raw [R,N,4], z [R,N], rays_d [R,3]; noise [R,N] already multiplied by
  * raw_noise_std, or NULL.  Outputs (any may be NULL): rgb [R,3], disp/acc/depth [R],
- * alphas/weights [R,N].  (density is raw[...,3], a view, and has no output here.)          */
+ * alphas/weights [R,N].  (density is raw[...,3], a view, and has no output here.)
+ * N == 1 reproduces the reference exactly: its dists/alphas/weights are then EMPTY ([R,0]), so
+ * rgb = sigmoid(raw rgb), acc = depth = 0, disp = 1e10 and alphas/weights are not written.    */
 int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d_dev,
                    const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
                    float* disp_dev, float* acc_dev, float* depth_dev, float* alphas_dev,

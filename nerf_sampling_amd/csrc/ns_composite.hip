@@ -93,6 +93,27 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
   }
 }
 
+// N == 1 (depth_only sampling, the training operator).  The reference builds `dists` from
+// z[..., 1:] - z[..., :-1] and a 1e10 column expanded to that EMPTY shape, so with one sample dists,
+// alphas and weights are [R, 0]: acc = depth = 0, disp = 1/1e-10, and rgb_map falls into the
+// `weights.shape[-1] == 0` branch: rgb_map = sum(sigmoid(raw rgb), -2) (sampling_trainer.py:174-220).
+__global__ void __launch_bounds__(256)
+raw2outputs_single_kernel(const float4* __restrict__ raw, int64_t R, float* __restrict__ rgb_out,
+                          float* __restrict__ disp_out, float* __restrict__ acc_out,
+                          float* __restrict__ depth_out) {
+  for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+    const float4 q = raw[r];
+    if (rgb_out) {
+      rgb_out[r * 3] = 1.0f / (1.0f + expf(-q.x));
+      rgb_out[r * 3 + 1] = 1.0f / (1.0f + expf(-q.y));
+      rgb_out[r * 3 + 2] = 1.0f / (1.0f + expf(-q.z));
+    }
+    if (disp_out) disp_out[r] = 1.0f / 1e-10f;
+    if (acc_out) acc_out[r] = 0.0f;
+    if (depth_out) depth_out[r] = 0.0f;
+  }
+}
+
 // ---- inverse-CDF sampling, run_nerf_helpers.py:250-293 -----------------------------------------
 // shared body: cdf (length nb) from weights (length nb-1), then one inverse lookup
 constexpr int kMaxBins = 512;
@@ -263,8 +284,11 @@ int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d
   hipStream_t s = ns::as_stream(stream);
 #define NS_R2O(SW) launch_r2o<SW>(raw_dev, z_dev, rays_d_dev, noise_dev, R, N, white_bkgd, rgb_dev, disp_dev, \
                                   acc_dev, depth_dev, alphas_dev, weights_dev, s)
-  if (N <= 1) NS_R2O(1);
-  else if (N <= 2) NS_R2O(2);
+  if (N == 1) {
+    // alphas / weights are [R, 0] in the reference for a single sample: nothing to write there
+    raw2outputs_single_kernel<<<ns::ew_grid(R, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(raw_dev), R,
+                                                                  rgb_dev, disp_dev, acc_dev, depth_dev);
+  } else if (N <= 2) NS_R2O(2);
   else if (N <= 4) NS_R2O(4);
   else if (N <= 8) NS_R2O(8);
   else if (N <= 16) NS_R2O(16);

@@ -255,8 +255,10 @@ def raw2outputs(raw: Tensor, z: Tensor, rays_d: Tensor, noise: Optional[Tensor] 
     disp = torch.empty((R,), dtype=torch.float32, device=dev)
     acc = torch.empty_like(disp)
     depth = torch.empty_like(disp)
-    alphas = torch.empty((R, N), dtype=torch.float32, device=dev) if want_per_sample else None
-    weights = torch.empty((R, N), dtype=torch.float32, device=dev) if want_per_sample else None
+    # one sample: the reference's alphas / weights are [R, 0] (see ns_raw2outputs in the header)
+    n_out = 0 if N == 1 else N
+    alphas = torch.empty((R, n_out), dtype=torch.float32, device=dev) if want_per_sample else None
+    weights = torch.empty((R, n_out), dtype=torch.float32, device=dev) if want_per_sample else None
     if noise is not None:
         noise = _dev(noise, "noise")
     check(lib.ns_raw2outputs(_ptr(raw), _ptr(z), _ptr(rays_d), _ptr(noise), R, N, int(bool(white_bkgd)),
