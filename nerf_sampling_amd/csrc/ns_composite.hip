@@ -32,7 +32,7 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
     float norm = 0.f;
     if (live) {
       const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
-      norm = sqrtf((dx * dx + dy * dy) + dz * dz);
+      norm = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));  // torch.norm: fma chain
     }
     float carry = 1.0f;
     float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;

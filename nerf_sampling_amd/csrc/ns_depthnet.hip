@@ -93,7 +93,7 @@ depthnet_kernel(DepthArgs a) {
     float x6[6];
     {
       const float b = 2.0f * ((d[0] * o[0] + d[1] * o[1]) + d[2] * o[2]);
-      const float on = sqrtf((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
+      const float on = sqrtf(__builtin_fmaf(o[2], o[2], __builtin_fmaf(o[1], o[1], o[0] * o[0])));  // torch.norm
       const float c = on * on - a.radius * a.radius;
       const float aa = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
       const float sq = sqrtf(b * b - 4.0f * aa * c);

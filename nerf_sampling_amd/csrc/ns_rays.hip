@@ -38,7 +38,8 @@ get_rays_kernel(Cam cam, int W, int row0, int64_t R, float near_, float far_,
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       d[c] = (dx * cam.r[3 * c + 0] + dy * cam.r[3 * c + 1]) + dz * cam.r[3 * c + 2];
-    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+    // torch.norm on the CPU accumulates squares as an fma chain (verified bit-for-bit on the golden rays)
+    const float nrm = sqrtf(__builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], d[0] * d[0])));
     if (rays_o) {
       rays_o[idx * 3 + 0] = cam.t[0]; rays_o[idx * 3 + 1] = cam.t[1]; rays_o[idx * 3 + 2] = cam.t[2];
     }
@@ -67,7 +68,7 @@ sphere_kernel(const float* __restrict__ o, const float* __restrict__ d, int64_t 
     const float ox = o[r * 3], oy = o[r * 3 + 1], oz = o[r * 3 + 2];
     const float dx = d[r * 3], dy = d[r * 3 + 1], dz = d[r * 3 + 2];
     const float b = 2.0f * ((dx * ox + dy * oy) + dz * oz);
-    const float on = sqrtf((ox * ox + oy * oy) + oz * oz);  // torch.norm(o)**2: sqrt, then square
+    const float on = sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox)));  // torch.norm(o)**2: sqrt, then square
     const float c = on * on - radius * radius;
     const float a = (dx * dx + dy * dy) + dz * dz;
     const float sq = sqrtf(b * b - 4.0f * a * c);           // NaN when the line misses

@@ -504,9 +504,24 @@ def _uniform_linear(rng: np.random.Generator, out_f: int, in_f: int, gain: float
     return torch.from_numpy(w), torch.from_numpy(b)
 
 
+
+def _decay_embedding_columns(w: Tensor, start: int, d: int, n_freqs: int) -> None:
+    """Scale the weight columns that multiply sin/cos(2^L x) by 2^-L (in place).
+
+    Trained radiance fields are smooth at the scale of fp32 rounding; an i.i.d. random first layer is
+    not (it weights the 2^9 band like the 2^0 band, so a 1-ulp change of a coordinate is amplified
+    ~500x and end-to-end comparisons measure conditioning, not kernels).  The 1/f decay gives the
+    synthetic scenes a realistic spectrum.  Column order: run_nerf_helpers.py:44-45.
+    """
+    for level in range(n_freqs):
+        lo = start + d + 2 * d * level
+        w[:, lo : lo + 2 * d] *= 2.0 ** (-level)
+
+
 def make_nerf_params(
     seed: int, D: int = 8, W: int = 256, input_ch: int = 63, input_ch_views: int = 27,
     skips=(4,), sigma_gain: float = 1.0, sigma_bias: float = 0.0, hidden_gain: float = 1.0,
+    spectral_decay: bool = False,
 ) -> Params:
     """Deterministic NeRF weights, nn.Linear-default-like U(+-1/sqrt(fan_in)) scale.
 
@@ -519,8 +534,12 @@ def make_nerf_params(
     for i in range(D):
         in_f = input_ch if i == 0 else (W + input_ch if (i - 1) in skips else W)
         w, b = _uniform_linear(rng, W, in_f, hidden_gain)
+        if spectral_decay and in_f != W:  # layers that see the embedded point (first 63 columns)
+            _decay_embedding_columns(w, 0, 3, (input_ch // 3 - 1) // 2)
         p[f"pts_linears.{i}.weight"], p[f"pts_linears.{i}.bias"] = w, b
     w, b = _uniform_linear(rng, W // 2, input_ch_views + W, hidden_gain)
+    if spectral_decay:
+        _decay_embedding_columns(w, W, 3, (input_ch_views // 3 - 1) // 2)
     p["views_linears.0.weight"], p["views_linears.0.bias"] = w, b
     w, b = _uniform_linear(rng, W, W, hidden_gain)
     p["feature_linear.weight"], p["feature_linear.bias"] = w, b
@@ -533,7 +552,7 @@ def make_nerf_params(
 
 def make_depthnet_params(
     seed: int, n_layers: int = 10, width: int = 256, multires: int = 10,
-    branch_gain: float = 1.0, trunk_gain: float = 1.0,
+    branch_gain: float = 1.0, trunk_gain: float = 1.0, spectral_decay: bool = False,
 ) -> Params:
     """Deterministic DepthNet weights; key names follow depth_net.py:103-107.
 
@@ -548,10 +567,21 @@ def make_depthnet_params(
         for i in range(n_layers):
             in_f = 2 * e if i == 0 else width + e
             w, b = _uniform_linear(rng, width, in_f, branch_gain)
+            if spectral_decay:
+                dch = 3 if e == e3 else 6
+                if i == 0:
+                    _decay_embedding_columns(w, 0, dch, multires)
+                    _decay_embedding_columns(w, e, dch, multires)
+                else:
+                    _decay_embedding_columns(w, width, dch, multires)
             p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"] = w, b
     for i in range(n_layers):
         in_f = 3 * width + 2 * e3 + e6 if i == 0 else width
         w, b = _uniform_linear(rng, width, in_f, trunk_gain)
+        if spectral_decay and i == 0:
+            _decay_embedding_columns(w, 3 * width, 3, multires)
+            _decay_embedding_columns(w, 3 * width + e3, 3, multires)
+            _decay_embedding_columns(w, 3 * width + 2 * e3, 6, multires)
         p[f"cat_layers.{2 * i}.weight"], p[f"cat_layers.{2 * i}.bias"] = w, b
     w, b = _uniform_linear(rng, 1, width, trunk_gain)
     p["to_depth.0.weight"], p["to_depth.0.bias"] = w, b
@@ -565,15 +595,15 @@ SQRT3, SQRT6 = math.sqrt(3.0), math.sqrt(6.0)
 SCENES = {
     # production sizes (run.py:101-109: n_layers 10, layer_width 256; NeRF 8x256)
     "lego_synth": dict(
-        coarse=dict(seed=12, D=8, W=256, hidden_gain=SQRT6, sigma_gain=150.0, sigma_bias=40.0),
-        fine=dict(seed=13, D=8, W=256, hidden_gain=SQRT6, sigma_gain=150.0, sigma_bias=60.0),
-        depth=dict(seed=7, n_layers=10, width=256, branch_gain=SQRT3, trunk_gain=SQRT6),
+        coarse=dict(seed=12, D=8, W=256, hidden_gain=SQRT6, sigma_gain=300.0, sigma_bias=45.0, spectral_decay=True),
+        fine=dict(seed=13, D=8, W=256, hidden_gain=SQRT6, sigma_gain=450.0, sigma_bias=115.0, spectral_decay=True),
+        depth=dict(seed=7, n_layers=10, width=256, branch_gain=SQRT3, trunk_gain=SQRT6, spectral_decay=True),
     ),
     # reduced sizes for fast CPU tests
     "tiny_synth": dict(
-        coarse=dict(seed=22, D=4, W=128, hidden_gain=SQRT6, sigma_gain=150.0, sigma_bias=40.0),
-        fine=dict(seed=23, D=4, W=128, hidden_gain=SQRT6, sigma_gain=150.0, sigma_bias=40.0),
-        depth=dict(seed=27, n_layers=3, width=128, branch_gain=SQRT3, trunk_gain=SQRT6),
+        coarse=dict(seed=22, D=4, W=128, hidden_gain=SQRT6, sigma_gain=300.0, sigma_bias=-30.0, spectral_decay=True),
+        fine=dict(seed=23, D=4, W=128, hidden_gain=SQRT6, sigma_gain=300.0, sigma_bias=43.0, spectral_decay=True),
+        depth=dict(seed=27, n_layers=3, width=128, branch_gain=SQRT3, trunk_gain=SQRT6, spectral_decay=True),
     ),
 }
 

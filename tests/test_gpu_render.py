@@ -1,0 +1,281 @@
+"""GPU parity tests, operator level: the mirrored reference API (render_rays_test / render_rays /
+render_test / sample_as_in_NeRF) through the HIP kernels against golden dicts captured from the
+reference, plus size-independent properties at the full BASELINE size (800x800, 64 samples/ray).
+
+fp32 gate: |rgb - reference| <= 1e-4 (BASELINE.json north_star) on every well-conditioned ray.
+A ray is ill-conditioned when the reference's own result moves by more than the gate under a
+perturbation of sigma the size of fp32 GEMM rounding noise (the last sample's alpha is
+1 - exp(-relu(sigma) * 1e10), a step function of sigma's sign); those rays are counted and must be rare.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def make_trainer(**over):
+    from nerf_sampling_amd.trainers import DepthNetTrainer
+
+    kw = dict(dataset_type="blender", basedir="/tmp", expname="golden", no_batching=True, datadir="/nonexistent",
+              half_res=True, white_bkgd=True, N_importance=128, N_samples=64, use_viewdirs=True,
+              input_dims_embed=3, device="cuda")
+    kw.update(over)
+    return DepthNetTrainer(**kw)
+
+
+def render_kwargs(trainer, m):
+    from nerf_sampling_amd.run_nerf_helpers import get_embedder
+
+    embed_fn, _ = get_embedder(trainer.multires, trainer.i_embed, 3)
+    embeddirs_fn, _ = get_embedder(trainer.multires_views, trainer.i_embed, 3)
+    query = lambda inputs, viewdirs, network_fn: trainer.run_network(  # noqa: E731
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=trainer.netchunk)
+    return dict(network_query_fn=query, perturb=0.0, N_importance=trainer.N_importance, network_fine=m["fine"],
+                N_samples=trainer.N_samples, network_fn=m["coarse"], use_viewdirs=True,
+                white_bkgd=trainer.white_bkgd, raw_noise_std=0.0, trainer=trainer, lindisp=trainer.lindisp,
+                depth_network=m["depth"], model_mode="test")
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def frac_bad(a, b, tol):
+    err = np.abs(a - b)
+    err = err.reshape(err.shape[0], -1).max(axis=1)
+    return float(np.mean(~(err <= tol))), err
+
+
+@pytest.fixture(autouse=True)
+def _fp32():
+    from nerf_sampling_amd import ops
+
+    ops.set_compute_dtype("f32")
+    yield
+    ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+@pytest.mark.parametrize("mode", ["depthnet", "full_nerf", "nerf_max", "compare"])
+def test_render_rays_test_modes(golden, gpu_modules, scene, mode):
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("render_rays_test")
+    m = gpu_modules(scene)
+    flags = {"full_nerf": dict(use_full_nerf=True), "nerf_max": dict(use_nerf_max_pts=True),
+             "compare": dict(compare_nerf=True), "depthnet": {}}[mode]
+    tr = make_trainer(n_depth_samples=32, sampling_mode="uniform", distance=0.1, **flags)
+    res = nerf_utils.render_rays_test(T(g["ray_batch"]).cuda(), **render_kwargs(tr, m))
+    prefix = f"{scene}_{mode}_"
+    keys = [k[len(prefix):] for k in g if k.startswith(prefix)]
+    assert set(keys) == set(res.keys())
+    # host/device placement contract of the reference (nerf_utils.py:820-822, 866-870)
+    assert res["depth_net_rgb_map"].is_cuda
+    for k in keys:
+        if k != "depth_net_rgb_map":
+            assert not res[k].is_cuda, k
+    for k in keys:
+        exp = g[prefix + k]
+        mine = npy(res[k])
+        assert mine.shape[1:] == exp.shape[1:], (k, mine.shape, exp.shape)
+        mine = mine[: exp.shape[0]]
+        if k in ("depth_net_z_vals", "depth_net_pts", "max_z_vals", "max_pts") and mode == "depthnet":
+            np.testing.assert_allclose(mine, exp, rtol=0, atol=3e-4, err_msg=k)   # DepthNet z: 5e-5 of [2,6]
+            continue
+        # hierarchical modes re-sample by inverting the coarse CDF, which has 1e-5-mass floor bins where a
+        # 1e-7 change of the CDF moves a sample by a bin width; gate on the fraction of rays and the median
+        hier = mode != "depthnet"
+        tol = 2e-4 if ("rgb" in k or "disp" in k) else (5e-3 if hier else 2e-4)
+        bad, err = frac_bad(mine, exp, tol)
+        assert bad <= 0.03, (k, bad, float(err.max()))
+        assert np.median(err) < (1e-3 if hier and "rgb" not in k and "disp" not in k else 5e-5), (k, float(np.median(err)))
+    if mode == "nerf_max":
+        assert res["depth_net_disp_map"].shape == (256, 3)        # reference quirk, nerf_utils.py:826
+
+
+@pytest.mark.parametrize("ns,mode,dist", [(2, "uniform", 0.01), (64, "uniform", 0.1), (1, "depth_only", 0.1)])
+def test_render_rays_test_sampling_setups(golden, gpu_modules, ns, mode, dist):
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("render_rays_test")
+    m = gpu_modules("lego_synth")
+    tr = make_trainer(n_depth_samples=ns, sampling_mode=mode, distance=dist)
+    res = nerf_utils.render_rays_test(T(g["ray_batch"]).cuda(), **render_kwargs(tr, m))
+    for k in ("depth_net_rgb_map", "depth_net_disp_map", "depth_net_weights", "depth_net_z_vals"):
+        exp = g[f"lego_synth_{mode}{ns}_{dist}_{k}"]
+        mine = npy(res[k])
+        assert mine.shape == exp.shape, (k, mine.shape, exp.shape)
+        if exp.size == 0:
+            continue
+        tol = 3e-4 if k == "depth_net_z_vals" else 2e-4
+        bad, err = frac_bad(mine, exp, tol)
+        assert bad <= 0.03 and np.median(err) < 5e-5, (k, bad, float(err.max()))
+
+
+def test_frame_config1_fp32_gate(golden, gpu_modules):
+    """BASELINE config 1 (64x64, 32 samples/ray) through render_test, fp32 gate 1e-4 on rgb and disp."""
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("frame64")
+    m = gpu_modules("lego_synth")
+    tr = make_trainer(n_depth_samples=32, sampling_mode="uniform", distance=0.1)
+    kw = render_kwargs(tr, m)
+    kw.update(near=2.0, far=6.0, ndc=False)
+    rgb, disp, extras = nerf_utils.render_test(64, 64, g["K"], chunk=1024 * 32, c2w=T(g["c2w"]), **kw)
+    assert rgb.shape == (64, 64, 3) and disp.shape == (64, 64)
+    assert extras["depth_net_z_vals"].shape == (64, 64, 32) and extras["rays_o"].shape == (4096, 3)
+    # sensitivity mask from the oracle: rays whose reference rgb moves > 1e-4 when sigma moves by 1e-4 * |sigma|_max
+    p = m["params"]
+    batch, o, d, _ = O.ray_batch_from_camera(64, 64, g["K"], T(g["c2w"]), 2.0, 6.0)
+    mean = O.depthnet_forward(p["depth"], o, d)
+    pts, z = O.place_samples(o, d, mean, 32, "uniform", 0.1)
+    raw = O.run_network(p["fine"], pts, batch[:, -3:])
+    eps = 1e-5 * float(raw[..., 3].abs().max())   # ~5x the measured fp32 sigma error (tools/gpu_diag.py)
+    base = O.raw2outputs(raw, z, d, 0.0, True)[0]
+    ill = torch.zeros(raw.shape[0], dtype=torch.bool)
+    for sgn in (-1.0, 1.0):
+        pert = raw.clone(); pert[..., 3] += sgn * eps
+        ill |= ((O.raw2outputs(pert, z, d, 0.0, True)[0] - base).abs().max(-1).values > 1e-4)
+    ill = ill.numpy()
+    err_rgb = np.abs(npy(rgb) - g["rgb"]).reshape(-1, 3).max(-1)
+    err_disp = np.abs(npy(disp) - g["disp"]).reshape(-1) / np.maximum(np.abs(g["disp"]).reshape(-1), 1.0)
+    print(f"config1: ill-conditioned rays {ill.mean():.4f}, max rgb err on the rest {err_rgb[~ill].max():.2e}, "
+          f"overall median {np.median(err_rgb):.2e}")
+    assert ill.mean() < 0.01
+    assert err_rgb[~ill].max() <= 1e-4
+    assert err_disp[~ill].max() <= 1e-4
+    assert np.mean(err_rgb > 1e-4) < 0.02
+    mse = float(((npy(rgb) - g["rgb"]) ** 2).mean())
+    assert -10 * np.log10(max(mse, 1e-20)) > 60.0   # PSNR(build || reference) in dB
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_render_rays_train_forward(golden, gpu_modules, scene):
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("render_rays_train")
+    m = gpu_modules(scene)
+    tr = make_trainer()
+    res = nerf_utils.render_rays(T(g["ray_batch"]).cuda(), **render_kwargs(tr, m))
+    assert set(res) == {"depth_net_rgb_map", "depth_net_disp_map", "depth_net_z_vals", "max_z_vals",
+                        "depth_net_pts", "max_pts", "raw"}
+    for k in ("depth_net_pts", "max_pts", "raw"):
+        assert not res[k].is_cuda                          # reference moves these to the host (:723-727)
+    for k, v in res.items():
+        exp = g[f"{scene}_{k}"]
+        mine = npy(v)
+        assert mine.shape == exp.shape, k
+        if k in ("depth_net_z_vals", "depth_net_pts"):
+            np.testing.assert_allclose(mine, exp, rtol=0, atol=3e-4)
+        elif k == "raw":
+            scale = np.abs(exp).reshape(-1, 4).max(0)
+            bad, err = frac_bad(mine / scale, exp / scale, 5e-4)   # points differ by the DepthNet z tolerance
+            assert bad <= 0.03, (k, bad)
+        elif k in ("max_z_vals", "max_pts"):
+            bad, err = frac_bad(mine, exp, 2e-3)
+            assert bad <= 0.05, (k, bad)                    # argmax over near-tied weights may pick a neighbour
+        else:
+            bad, err = frac_bad(mine, exp, 5e-4)
+            assert bad <= 0.03, (k, bad, float(err.max()))
+
+
+@pytest.mark.parametrize("lindisp", [True, False])
+def test_sample_as_in_nerf(golden, gpu_modules, lindisp):
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("hierarchical")
+    m = gpu_modules("tiny_synth")
+    tr = make_trainer(lindisp=lindisp)
+    kw = render_kwargs(tr, m)
+    res = nerf_utils.sample_as_in_NeRF(ray_batch=T(g["ray_batch"]).cuda(), network_fn=kw["network_fn"],
+                                       network_fine=kw["network_fine"], network_query_fn=kw["network_query_fn"],
+                                       N_samples=64, trainer=tr, perturb=0.0, raw_noise_std=0.0, lindisp=lindisp,
+                                       white_bkgd=True, kwargs={}, pytest=False)
+    names = ("density", "z", "pts", "rgb_map", "weights", "alphas", "disp", "raw")
+    assert res[1].shape == (96, 192)
+    got = {nm: npy(v) for nm, v in zip(names, res)}
+    exp = {nm: g[f"tiny_synth_lin{int(lindisp)}_{nm}"] for nm in names}
+    # sample positions: inverse-CDF samples in floor bins are ill-conditioned (see above); the rest is tight
+    bad, err = frac_bad(got["z"], exp["z"], 5e-3)
+    assert bad <= 0.03 and np.median(np.abs(got["z"] - exp["z"])) < 1e-5, (bad, float(err.max()))
+    assert (got["z"][:, 1:] >= got["z"][:, :-1]).all()
+    np.testing.assert_allclose(got["pts"], npy(res[1])[..., None] * g["ray_batch"][:, None, 3:6] + g["ray_batch"][:, None, 0:3],
+                               rtol=1e-6, atol=1e-6)
+    # rendered outputs
+    for nm, tol in (("rgb_map", 2e-4), ("disp", 2e-4)):
+        scale = np.maximum(np.abs(exp[nm]), 1.0) if nm == "disp" else 1.0
+        bad, err = frac_bad(got[nm] / scale, exp[nm] / scale, tol)
+        assert bad <= 0.03 and np.median(err) < 5e-5, (nm, bad, float(np.median(err)))
+    # per-sample outputs live at the (slightly moved) sample positions: compare where the positions agree
+    same = np.abs(got["z"] - exp["z"]) < 1e-6
+    assert same.mean() > 0.5
+    scale = np.abs(exp["raw"]).reshape(-1, 4).max(0)
+    assert (np.abs(got["raw"] - exp["raw"]) / scale)[same].max() < 1e-3
+    assert np.allclose(got["density"], got["raw"][..., 3])
+
+
+def test_fused_matches_operator_chain(gpu_modules):
+    """ns_render_rays_depthnet (one C call, camera rays generated on the device) == the operator chain."""
+    from nerf_sampling_amd import nerf_utils, ops
+
+    m = gpu_modules("lego_synth")
+    H = W = 48
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(-63.0, -30.0, 4.0)[:3, :4]
+    tr = make_trainer(n_depth_samples=64, sampling_mode="uniform", distance=0.1)
+    kw = render_kwargs(tr, m)
+    kw.update(near=2.0, far=6.0, ndc=False)
+    rgb, disp, extras = nerf_utils.render_test(H, W, K, chunk=1024 * 32, c2w=c2w, **kw)
+    out = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                   camera=(H, W, K, c2w, 0, H), n_samples=64, mode="uniform", std=0.1, extras=True)
+    assert torch.equal(out["rgb"].reshape(H, W, 3), rgb)         # same kernels, same inputs: bit exact
+    assert torch.equal(out["disp"].reshape(H, W), disp.cuda())
+    assert torch.equal(out["z"].cpu().reshape(H, W, 64), extras["depth_net_z_vals"])
+    assert torch.equal(out["weights"].cpu().reshape(H, W, 64), extras["depth_net_weights"])
+    # row sharding: two half-frames concatenated == the full frame (what the multi-GPU path relies on)
+    top = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                   camera=(H, W, K, c2w, 0, H // 2), n_samples=64, mode="uniform", std=0.1)
+    bot = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                   camera=(H, W, K, c2w, H // 2, H), n_samples=64, mode="uniform", std=0.1)
+    assert torch.equal(torch.cat([top["rgb"], bot["rgb"]]), out["rgb"])
+
+
+@pytest.mark.parametrize("dtype,min_psnr", [("bf16", 18.0), ("f16", 25.0)])
+def test_full_size_frame_properties(gpu_modules, dtype, min_psnr):
+    """BASELINE config 2 size (800x800, DepthNet + 64 samples/ray): size-independent properties of the
+    16-bit MFMA path, and PSNR against the fp32 path of the same build on a 200-row band.
+
+    The PSNR floor is low on purpose: the reference composites the last sample with dist = 1e10, so a
+    ray's colour is a step function of the sign of its last sigma, and on the synthetic scene ~5-15 % of
+    rays have |sigma_last| inside the 16-bit operand noise.  Median error and the raw-level tests in
+    test_gpu_kernels.py are the meaningful 16-bit accuracy statements."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("lego_synth")
+    H = W = 800
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    out = ops.render_rays_depthnet(m["depth"].packed(dtype), m["fine"].packed(dtype), camera=(H, W, K, c2w, 0, H),
+                                   n_samples=64, mode="uniform", std=0.1, extras=True)
+    rgb, w, z = out["rgb"], out["weights"], out["z"]
+    assert rgb.shape == (H * W, 3) and torch.isfinite(rgb).all()
+    assert float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1.0 + 1e-5        # white background compositing
+    assert (w >= 0).all() and float(w.sum(-1).max()) <= 1.0 + 1e-4              # weights are a sub-partition of 1
+    assert (z[:, 1:] >= z[:, :-1]).all() and float(z.min()) >= 2.0 and float(z.max()) <= 6.0
+    band = (300, 500)
+    lo = ops.render_rays_depthnet(m["depth"].packed(dtype), m["fine"].packed(dtype),
+                                  camera=(H, W, K, c2w, band[0], band[1]), n_samples=64, mode="uniform", std=0.1)
+    assert torch.equal(lo["rgb"], rgb[band[0] * W : band[1] * W])               # shard == slice of the frame
+    ref = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                   camera=(H, W, K, c2w, band[0], band[1]), n_samples=64, mode="uniform", std=0.1)
+    mse = float(((lo["rgb"] - ref["rgb"]) ** 2).mean())
+    psnr = -10 * np.log10(max(mse, 1e-20))
+    med = float((lo["rgb"] - ref["rgb"]).abs().max(-1).values.median())
+    print(f"{dtype}: PSNR vs fp32 path on rows {band} = {psnr:.2f} dB, median |rgb err| = {med:.2e}")
+    assert psnr > min_psnr
+    assert med < (2e-3 if dtype == "bf16" else 3e-4)
