@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/sec at 800x800, DepthNet + 64 samples/ray (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one full 800x800 frame of the reference's spiral render path (pose k of 40): ray generation,
+DepthNet, sample placement, NeRF MLP and compositing, all on the device, plus -- for N > 1 -- the single
+all-gather that assembles the frame.  Frames are row-sharded over the N ranks (total work fixed: strong
+scaling).  Weights are the seeded synthetic "lego_synth" scene (no dataset / checkpoint ships with the
+reference); inputs are 16 camera scalars, so nothing is staged from the host inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work, SURVEY.md section 8(a): MACs counted on the reference's arithmetic, no padding credit
+NERF_FLOP_PER_SAMPLE = 2 * 593_408
+DEPTHNET_FLOP_PER_RAY = 2 * 3_330_304
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
+
+
+def build_modules(scene_name, device):
+    from nerf_sampling_amd import synthetic
+    from nerf_sampling_amd.depth_net import DepthNet
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+    cfg, params = synthetic.SCENES[scene_name], synthetic.make_scene(scene_name)
+    fine = NeRF(D=cfg["fine"]["D"], W=cfg["fine"]["W"], input_ch=63, input_ch_views=27, output_ch=5, skips=[4],
+                use_viewdirs=True)
+    fine.load_state_dict(params["fine"])
+    n, w = cfg["depth"]["n_layers"], cfg["depth"]["width"]
+    dn = DepthNet(hidden_sizes=[w] * n, cat_hidden_sizes=[w] * n, sphere_radius=2.0)
+    dn.load_state_dict(params["depth"])
+    return fine.to(device), dn.to(device), params
+
+
+def host_cores() -> int:
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 32)  # one GPU's share of the host; more threads than that only oversubscribes
+
+
+def cpu_baseline(params, H, W, K, c2w, n_samples, rows, budget_s=20.0):
+    """The oracle (CPU port of the reference path: DepthNet -> placement -> NeRF MLP in 65536-row sub-chunks ->
+    compositing) timed on the host cores over a band of rows of the same frame, for at most ~budget_s."""
+    from oracle import nerf_oracle as O
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    batch, _, _, _ = O.ray_batch_from_camera(H, W, K, c2w, 2.0, 6.0)
+    batch = batch[rows[0] * W : rows[1] * W]
+    kw = dict(p_coarse=params["coarse"], p_fine=params["fine"], p_depth=params["depth"], n_depth_samples=n_samples,
+              sampling_mode="uniform", distance=0.1)
+    chunk, done = 4096, 0
+    with torch.no_grad():
+        O.render_rays_test(batch[:1024], **kw)  # warm the thread pool / allocator
+        t0 = time.perf_counter()
+        while done < batch.shape[0] and time.perf_counter() - t0 < budget_s:
+            O.render_rays_test(batch[done : done + chunk], **kw)
+            done = min(batch.shape[0], done + chunk)
+        dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{done} rays from rows {rows[0]}-{rows[1]} of the same {H}x{W} frame, fp32 torch-CPU oracle, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--scene", default="lego_synth")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=50, help="rows of the frame timed on the CPU (x 800 rays)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from nerf_sampling_amd import ops, synthetic
+    from nerf_sampling_amd.parallel import FrameRenderer, hip_row_renderer
+
+    H = W = args.size
+    _, K = synthetic.blender_intrinsics(H, W)
+    poses = synthetic.render_poses(40)[:, :3, :4]
+    fine, dn, params = build_modules(args.scene, device)
+    nerf_w, depth_w = fine.packed(args.dtype), dn.packed(args.dtype)
+    events = []
+    renderer = FrameRenderer(H, W, hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1,
+                                                    device=device, events=events), device)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        renderer.render(poses[i % 40])
+    events.clear()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rgb, disp = renderer.render(poses[(args.warmup + i) % 40])
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(rgb).all()
+
+    # dominant kernel (NeRF MLP), timed with HIP events on its own stream inside the timed region
+    mlp_ms = float(np.mean([b.elapsed_ms(e) for b, e in events])) if events else float("nan")
+    rays_per_launch = renderer.rays_per_rank
+    mlp_flop = rays_per_launch * args.samples * NERF_FLOP_PER_SAMPLE
+    achieved = mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else float("nan")
+    peak = PEAK_TFLOPS[args.dtype]
+
+    if rank == 0:
+        rays = H * W * args.steps
+        out = {
+            "metric": "rays/sec at 800x800, 64 samples/ray; PSNR vs reference",
+            "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "
+                                   f"(std 0.1) through the NeRF 8x256 fine MLP, seeded synthetic weights ({args.scene}), "
+                                   "spiral render poses of load_blender.py",
+                       "rays_per_step": H * W, "samples_per_ray": args.samples,
+                       "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
+            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            mid = H // 2
+            rows = (mid - args.cpu_rows // 2, mid - args.cpu_rows // 2 + args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(params, H, W, K, poses[args.warmup % 40], args.samples, rows)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -171,9 +171,20 @@ typedef struct ns_render_args {
   float* z_dev;       /* [R,N] or NULL */
   float* weights_dev; /* [R,N] or NULL */
   float* pts_dev;     /* [R,N,3] or NULL */
+  /* optional hipEvent_t pair recorded on `stream` immediately before / after the NeRF-MLP kernel
+   * (the dominant kernel), so a harness can time it inside its own timed region; NULL = none   */
+  void* ev_mlp_begin;
+  void* ev_mlp_end;
 } ns_render_args;
 int64_t ns_render_workspace_bytes(int64_t R, int N);
 int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
+
+/* ---- timing helpers (hipEvent_t as void*) used by bench.py for the live roofline figure --------- */
+int ns_event_create(void** ev);
+void ns_event_destroy(void* ev);
+int ns_event_record(void* ev, void* stream);
+/* milliseconds between two recorded events; blocks until `end` has completed */
+int ns_event_elapsed_ms(void* begin, void* end, float* ms);
 
 #ifdef __cplusplus
 }

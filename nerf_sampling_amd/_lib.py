@@ -36,6 +36,7 @@ class RenderArgs(C.Structure):
         ("near_", _f), ("far_", _f), ("sphere_radius", _f), ("white_bkgd", _i),
         ("workspace_dev", _p),
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("pts_dev", _p),
+        ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
     ]
 
 
@@ -65,6 +66,10 @@ SIGNATURES = {
     "ns_argmax_gather": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ns_render_workspace_bytes": (_i64, [_i64, _i]),
     "ns_render_rays_depthnet": (_i, [C.POINTER(RenderArgs), _p]),
+    "ns_event_create": (_i, [C.POINTER(_p)]),
+    "ns_event_destroy": (None, [_p]),
+    "ns_event_record": (_i, [_p, _p]),
+    "ns_event_elapsed_ms": (_i, [_p, _p, C.POINTER(_f)]),
 }
 
 _lib = None

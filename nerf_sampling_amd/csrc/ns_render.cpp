@@ -70,10 +70,37 @@ int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   if (rc != NS_OK) return rc;
   rc = ns_place_samples(a->mode, o, d, mean, a->noise_dev, R, N, a->std_, a->pts_dev, z, stream);
   if (rc != NS_OK) return rc;
+  if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
   rc = ns_nerf_forward(a->nerf, nullptr, o, d, z, view, R, N, raw, stream);
   if (rc != NS_OK) return rc;
+  if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
   return ns_raw2outputs(raw, z, d, nullptr, R, N, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr, nullptr,
                         a->weights_dev, stream);
+}
+
+int ns_event_create(void** ev) {
+  NS_REQUIRE(ev, "null pointer");
+  hipEvent_t e;
+  NS_HIP(hipEventCreate(&e));
+  *ev = e;
+  return NS_OK;
+}
+
+void ns_event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+}
+
+int ns_event_record(void* ev, void* stream) {
+  NS_REQUIRE(ev, "null event");
+  NS_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), ns::as_stream(stream)));
+  return NS_OK;
+}
+
+int ns_event_elapsed_ms(void* begin, void* end, float* ms) {
+  NS_REQUIRE(begin && end && ms, "null pointer");
+  NS_HIP(hipEventSynchronize(static_cast<hipEvent_t>(end)));
+  NS_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(begin), static_cast<hipEvent_t>(end)));
+  return NS_OK;
 }
 
 }  // extern "C"

@@ -351,7 +351,7 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
                          n_samples: int, mode: str, std: float, noise: Optional[Tensor] = None,
                          near: float = 2.0, far: float = 6.0, sphere_radius: float = 2.0,
                          white_bkgd: bool = True, extras: bool = False, workspace: Optional[RenderWorkspace] = None,
-                         device="cuda"):
+                         device="cuda", mlp_events=None):
     """DepthNet -> placement -> NeRF MLP -> compositing as one C call.
 
     rays = (o, d, viewdirs) device tensors, or camera = (H, W, K, c2w, row0, row1) to generate
@@ -398,5 +398,31 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
         out["weights"] = torch.empty((R, N), dtype=torch.float32, device=device)
         out["pts"] = torch.empty((R, N, 3), dtype=torch.float32, device=device)
         a.z_dev, a.weights_dev, a.pts_dev = out["z"].data_ptr(), out["weights"].data_ptr(), out["pts"].data_ptr()
+    if mlp_events is not None:
+        a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
     check(lib.ns_render_rays_depthnet(C.byref(a), _stream(device)), "ns_render_rays_depthnet")
     return out
+
+
+class Event:
+    """hipEvent wrapper for timing a kernel on the stream it is launched on."""
+
+    def __init__(self):
+        self.handle = C.c_void_p()
+        check(_lib.load().ns_event_create(C.byref(self.handle)), "ns_event_create")
+
+    def record(self, device="cuda"):
+        check(_lib.load().ns_event_record(self.handle, _stream(torch.device(device))), "ns_event_record")
+
+    def elapsed_ms(self, end: "Event") -> float:
+        ms = C.c_float()
+        check(_lib.load().ns_event_elapsed_ms(self.handle, end.handle, C.byref(ms)), "ns_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().ns_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,78 @@
+"""Ray-range data parallelism over the GPUs of one node: contiguous image-row shards, one all-gather.
+
+The reference is single-process; rays are independent and the weights are
+read-only, so rank r renders rows [r*H/N, (r+1)*H/N) generating its own rays from the broadcast camera
+scalars (no scatter), and ONE all_gather_into_tensor of the [rows, W, 4] (rgb + disp) shard assembles the
+frame on every rank.  backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def row_range(H: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(row0, row1, rows_per_rank): equal contiguous shards; trailing ranks may get fewer (or no) rows."""
+    per = (H + world - 1) // world
+    r0 = min(H, rank * per)
+    return r0, min(H, r0 + per), per
+
+
+class FrameRenderer:
+    """Renders full frames, sharded by rows over the ranks of ``group``.
+
+    ``render_rows(c2w, row0, row1) -> (rgb [R,3], disp [R])`` produces this rank's shard; the default
+    is the fused HIP path (ops.render_rays_depthnet) with rays generated on the device.
+    """
+
+    def __init__(self, H: int, W: int, render_rows: Callable, device, group=None):
+        self.H, self.W, self.render_rows, self.device, self.group = H, W, render_rows, torch.device(device), group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.row0, self.row1, self.per = row_range(H, self.rank, self.world)
+        self.shard = torch.zeros((self.per * W, 4), dtype=torch.float32, device=self.device)
+        self.frame = (torch.empty((self.world * self.per * W, 4), dtype=torch.float32, device=self.device)
+                      if self.world > 1 else None)
+
+    @property
+    def rays_per_rank(self) -> int:
+        return (self.row1 - self.row0) * self.W
+
+    def render(self, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
+        """rgb [H,W,3], disp [H,W] of the whole frame, on every rank."""
+        n = self.rays_per_rank
+        if n > 0:
+            rgb, disp = self.render_rows(c2w, self.row0, self.row1)
+            self.shard[:n, :3] = rgb
+            self.shard[:n, 3] = disp
+        if self.world == 1:
+            full = self.shard
+        else:
+            dist.all_gather_into_tensor(self.frame, self.shard, group=self.group)
+            full = self.frame
+        full = full[: self.H * self.W]
+        return full[:, :3].reshape(self.H, self.W, 3), full[:, 3].reshape(self.H, self.W)
+
+
+def hip_row_renderer(depthnet, nerf, H: int, W: int, K, n_samples: int, mode: str, std: float, near: float = 2.0,
+                     far: float = 6.0, sphere_radius: float = 2.0, device="cuda", events: Optional[list] = None):
+    """render_rows callable over the fused HIP path.  ``events``: list the (begin, end) hipEvent pair of the
+    NeRF-MLP kernel of each call is appended to (bench.py's live roofline timing)."""
+    from . import ops
+
+    ws = ops.RenderWorkspace()
+
+    def render_rows(c2w, row0, row1):
+        ev = None
+        if events is not None:
+            ev = (ops.Event(), ops.Event())
+            events.append(ev)
+        out = ops.render_rays_depthnet(depthnet, nerf, camera=(H, W, K, c2w, row0, row1), n_samples=n_samples,
+                                       mode=mode, std=std, near=near, far=far, sphere_radius=sphere_radius,
+                                       workspace=ws, device=device, mlp_events=ev)
+        return out["rgb"], out["disp"]
+
+    return render_rows
