@@ -43,18 +43,18 @@ __device__ __forceinline__ void stash_load(const char* base, typename M::Block (
 }
 
 // one skip branch: h = e; layer 0 on cat[e, e]; layers >= 1 on cat[h, e]; no activation
-template <class M, int NB, int EBLK, int NWAVES>
-__device__ __forceinline__ void branch(Ring<NWAVES>& ring, f32x16 (&acc)[NB], typename M::Block (&hcur)[NB],
+template <class M, int NB, int EBLK, class PipeT>
+__device__ __forceinline__ void branch(PipeT& ring, f32x16 (&acc)[NB], typename M::Block (&hcur)[NB],
                                        const typename M::Block (&e)[EBLK], const float*& bias, int n_layers,
                                        int h) {
   init_bias<NB>(acc, bias, h); bias += NB * 32;
-  consume<M, NB, EBLK, NWAVES>(ring, acc, e);
-  consume<M, NB, EBLK, NWAVES>(ring, acc, e);
+  consume<M, NB, EBLK>(ring, acc, e);
+  consume<M, NB, EBLK>(ring, acc, e);
   to_blocks<M, kNone, NB>(hcur, acc);
   for (int i = 1; i < n_layers; ++i) {
     init_bias<NB>(acc, bias, h); bias += NB * 32;
-    consume<M, NB, NB, NWAVES>(ring, acc, hcur);
-    consume<M, NB, EBLK, NWAVES>(ring, acc, e);
+    consume<M, NB, NB>(ring, acc, hcur);
+    consume<M, NB, EBLK>(ring, acc, e);
     to_blocks<M, kNone, NB>(hcur, acc);
   }
 }
@@ -68,11 +68,12 @@ depthnet_kernel(DepthArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5;
 
-  float* bias_lds = reinterpret_cast<float*>(smem + kRingDepth * kSlabBytes);
+  using PipeT = Pipe<M, NWAVES, 0>;
+  float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
   for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
   __syncthreads();
 
-  Ring<NWAVES> ring;
+  PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
 
   char* stash = a.scratch + (static_cast<size_t>(blockIdx.x) * NWAVES + wave) * 2 * NB * 64 * sizeof(Block);
@@ -108,47 +109,47 @@ depthnet_kernel(DepthArgs a) {
     {
       Block e3[2];
       embed3<M, PRECISE_TRIG, 10, 2>(e3, o, h);
-      branch<M, NB, 2, NWAVES>(ring, acc, hcur, e3, bias, a.n_layers, h);
+      branch<M, NB, 2>(ring, acc, hcur, e3, bias, a.n_layers, h);
       stash_store<M, NB>(stash, hcur, lane);
       embed3<M, PRECISE_TRIG, 10, 2>(e3, d, h);
-      branch<M, NB, 2, NWAVES>(ring, acc, hcur, e3, bias, a.n_layers, h);
+      branch<M, NB, 2>(ring, acc, hcur, e3, bias, a.n_layers, h);
       stash_store<M, NB>(stash + kStashBranch, hcur, lane);
     }
     {
       Block e6[4];
       embed6<M, PRECISE_TRIG>(e6, x6, h);
-      branch<M, NB, 4, NWAVES>(ring, acc, hcur, e6, bias, a.n_layers, h);
+      branch<M, NB, 4>(ring, acc, hcur, e6, bias, a.n_layers, h);
       // trunk layer 0, K-segments in the order h_x, e_x, h_o, e_o, h_d, e_d
       init_bias<NB>(acc, bias, h); bias += NB * 32;
-      consume<M, NB, NB, NWAVES>(ring, acc, hcur);
-      consume<M, NB, 4, NWAVES>(ring, acc, e6);
+      consume<M, NB, NB>(ring, acc, hcur);
+      consume<M, NB, 4>(ring, acc, e6);
     }
     {
       Block e3[2];
       stash_load<M, NB>(stash, hcur, lane);
-      consume<M, NB, NB, NWAVES>(ring, acc, hcur);
+      consume<M, NB, NB>(ring, acc, hcur);
       embed3<M, PRECISE_TRIG, 10, 2>(e3, o, h);
-      consume<M, NB, 2, NWAVES>(ring, acc, e3);
+      consume<M, NB, 2>(ring, acc, e3);
       stash_load<M, NB>(stash + kStashBranch, hcur, lane);
-      consume<M, NB, NB, NWAVES>(ring, acc, hcur);
+      consume<M, NB, NB>(ring, acc, hcur);
       embed3<M, PRECISE_TRIG, 10, 2>(e3, d, h);
-      consume<M, NB, 2, NWAVES>(ring, acc, e3);
+      consume<M, NB, 2>(ring, acc, e3);
     }
     to_blocks<M, kLeaky, NB>(hcur, acc);
     for (int i = 1; i < a.n_layers; ++i) {
       init_bias<NB>(acc, bias, h); bias += NB * 32;
-      consume<M, NB, NB, NWAVES>(ring, acc, hcur);
+      consume<M, NB, NB>(ring, acc, hcur);
       to_blocks<M, kLeaky, NB>(hcur, acc);
     }
     f32x16 acc1[1];
     init_bias<1>(acc1, bias, h);
-    consume<M, 1, NB, NWAVES>(ring, acc1, hcur);
+    consume<M, 1, NB>(ring, acc1, hcur);
     if (valid && h == 0) {
       const float depth = 1.0f / (1.0f + expf(-acc1[0][0]));
       a.z[r] = a.near_ * (1.0f - depth) + a.far_ * depth;  // depth_net.py:168
     }
   }
-  ring.drain();
+  ring.finish();
 }
 
 int depthnet_program_slabs(int cpb, int NB, int n) {
@@ -164,7 +165,7 @@ int depthnet_program_slabs(int cpb, int NB, int n) {
 
 template <class M, int NB, int NWAVES, bool PRECISE>
 int launch(const ns_weights* net, DepthArgs& a, hipStream_t stream) {
-  const size_t lds = static_cast<size_t>(kRingDepth) * kSlabBytes + static_cast<size_t>(a.bias_floats) * 4;
+  const size_t lds = static_cast<size_t>(Pipe<M, NWAVES, 0>::kLdsBytes) + static_cast<size_t>(a.bias_floats) * 4;
   if (lds > 160 * 1024) {
     ns::set_error("ns_depthnet_forward: %zu bytes of LDS needed (too many layers for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;

@@ -12,9 +12,10 @@
 //     exact order the MFMAs consume them (ns_pack.hip), so that one
 //     global_load_lds_dwordx4 per wave-instruction lands a chunk in LDS and one conflict-free
 //     ds_read_b128 per lane fetches an A fragment.  Chunks are grouped into 16-KiB slabs; all
-//     waves of a workgroup walk the same slab sequence through a ring of LDS slots with ONE
-//     s_barrier per slab and counted s_waitcnt vmcnt(N), so the DMA of slab t+2 is in flight
-//     while slab t feeds the matrix cores.
+//     waves of a workgroup walk the same slab sequence through a ring of 4 LDS slots with ONE
+//     s_barrier per slab and counted s_waitcnt vmcnt(N) (never 0 in the loop): while slab t feeds
+//     the matrix cores, slab t+1 has landed (so A fragments are read 4 chunks ahead of their MFMA,
+//     across slab seams), slab t+2 is in flight and slab t+3 is being issued.
 //   * Within a 32-feature block, lane half h (= lane >> 5) holds the 16 features
 //     k = 32*blk + (q & 3) + 8*(q >> 2) + 4*h, q = 0..15  (the MFMA C/D register map).  The
 //     host packer applies the same map to the weight columns, so any per-lane assignment of
@@ -36,7 +37,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int kChunkBytes = 1024;
 constexpr int kSlabChunks = 16;
 constexpr int kSlabBytes = kChunkBytes * kSlabChunks;
-constexpr int kRingDepth = 3;
+constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (read-ahead), in flight, being issued
+constexpr int kFragDepth = 4;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -59,9 +61,18 @@ struct MmaBF16 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { b.v[0][j] = (__bf16)x[j]; b.v[1][j] = (__bf16)x[8 + j]; }
   }
+  __device__ static __forceinline__ void relu_packed(Block& b) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      s16x8 v = __builtin_bit_cast(s16x8, b.v[i]);
+      v = __builtin_elementwise_max(v, (s16x8)(0));
+      b.v[i] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  using AFrag = bf16x8;
   template <int SUB>
-  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(a_lds);
+  __device__ static __forceinline__ void mma(f32x16& acc, const AFrag& a, const Block& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b.v[SUB], acc, 0, 0, 0);
   }
 };
@@ -75,9 +86,18 @@ struct MmaF16 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { b.v[0][j] = (_Float16)x[j]; b.v[1][j] = (_Float16)x[8 + j]; }
   }
+  __device__ static __forceinline__ void relu_packed(Block& b) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      s16x8 v = __builtin_bit_cast(s16x8, b.v[i]);
+      v = __builtin_elementwise_max(v, (s16x8)(0));
+      b.v[i] = __builtin_bit_cast(f16x8, v);
+    }
+  }
+  using AFrag = f16x8;
   template <int SUB>
-  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
-    const f16x8 a = *reinterpret_cast<const f16x8*>(a_lds);
+  __device__ static __forceinline__ void mma(f32x16& acc, const AFrag& a, const Block& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.v[SUB], acc, 0, 0, 0);
   }
 };
@@ -91,9 +111,10 @@ struct MmaF32 {
 #pragma unroll
     for (int j = 0; j < 16; ++j) b.v[j] = x[j];
   }
+  __device__ static __forceinline__ void relu_packed(Block&) {}
+  using AFrag = f32x4;
   template <int SUB>
-  __device__ static __forceinline__ void mma(f32x16& acc, const char* a_lds, const Block& b) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(a_lds);
+  __device__ static __forceinline__ void mma(f32x16& acc, const AFrag& a, const Block& b) {
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b.v[4 * SUB + e], acc, 0, 0, 0);
@@ -110,24 +131,34 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 #define NS_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 #define NS_GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 
-template <int NWAVES>
-struct Ring {
+// Ring of kRingDepth LDS slots + a kFragDepth-deep register pipeline of A fragments.
+//
+// Slab timeline (t = slab being multiplied):  slot t%4 is read by the MFMAs, slot (t+1)%4 has landed
+// and feeds the fragment read-ahead across the slab seam, slab t+2 is in flight, and slab t+3 is
+// issued right after the barrier that opens slab t into the slot slab t-1 just vacated.  Every DS
+// read is issued kFragDepth chunks before the MFMA that consumes it, so neither the LDS latency nor
+// the barrier sits on the MFMA critical path.
+//
+// LAG > 0 staggers the second half of the workgroup's waves (the SIMD partners of the first half:
+// MI355X_MICROARCH.md "Two waves per SIMD", item 9) LAG slabs behind the first half, so that one
+// partner's layer epilogue / tile prologue (VALU, global loads) runs under the other's MFMAs instead
+// of both leaving the matrix pipe idle at once.  It costs LAG more ring slots.
+template <class M, int NWAVES, int LAG = 0>
+struct Pipe {
+  using AFrag = typename M::AFrag;
   static constexpr int LPW = kSlabChunks / NWAVES;  // DMA instructions per wave per slab
-  const char* stream;   // device weight stream, n_slabs * 16 KiB
-  char* lds;            // ring base in LDS (kRingDepth slots)
+  static constexpr int RING = kRingBase + LAG;
+  static constexpr int kLdsBytes = RING * kSlabBytes;
+  const char* stream;   // device weight stream, n_slabs * 16 KiB, cyclic
+  char* lds;            // ring base in LDS
   uint32_t n_slabs;
-  uint32_t issue_slab;  // next slab of the stream to fetch (wraps: the stream is cyclic per tile)
+  uint32_t issue_slab;  // next slab of the stream to fetch
   uint32_t issue_slot;
-  uint32_t read_slot;
+  uint32_t read_slot;   // slot of the slab the next begin_slab() opens
   int wave, lane;
-
-  __device__ __forceinline__ void init(const char* stream_, char* lds_, uint32_t n_slabs_, int wave_,
-                                       int lane_) {
-    stream = stream_; lds = lds_; n_slabs = n_slabs_; wave = wave_; lane = lane_;
-    issue_slab = 0; issue_slot = 0; read_slot = 0;
-#pragma unroll
-    for (int s = 0; s < kRingDepth - 1; ++s) issue();
-  }
+  const char* cur;      // this lane's read pointer into the open slab (chunk c at +c*1024)
+  const char* nxt;      // ... and into the following one
+  AFrag f[kFragDepth];  // fragments of the next kFragDepth chunks
 
   __device__ __forceinline__ void issue() {
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + lane * 16;
@@ -139,50 +170,93 @@ struct Ring {
                                        NS_LDS_PTR(dst + chunk * kChunkBytes), 16, 0, 0);
     }
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
-    issue_slot = (issue_slot + 1 == kRingDepth) ? 0u : issue_slot + 1;
+    issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
   }
 
-  // Make the next slab readable and start the fetch of the one kRingDepth-1 ahead.
-  // Returns this lane's read pointer into the slab (chunk c is at +c*1024).
-  __device__ __forceinline__ const char* advance() {
-    // (1) my own DMA pieces of the slab about to be read have landed: only the
-    //     (kRingDepth-2) younger slabs' pieces may still be in flight.  lgkmcnt(0): every
-    //     ds_read of the previous slab has returned before its slot can be refilled.
-    if constexpr (LPW * (kRingDepth - 2) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if constexpr (LPW * (kRingDepth - 2) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    // (2) ... and everyone else's; all waves are also done with the previous slab
+  template <int N>
+  __device__ static __forceinline__ void wait_vm() {
+    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "unexpected DMA count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+
+  __device__ __forceinline__ AFrag load(const char* p) const { return *reinterpret_cast<const AFrag*>(p); }
+
+  __device__ __forceinline__ void init(const char* stream_, char* lds_, uint32_t n_slabs_, int wave_, int lane_) {
+    stream = stream_; lds = lds_; n_slabs = n_slabs_; wave = wave_; lane = lane_;
+    issue_slab = 0; issue_slot = 0; read_slot = 0;
+    issue(); issue(); issue();                    // slabs 0, 1, 2
+    wait_vm<2 * LPW>();                           // my pieces of slab 0 have landed ...
+    __builtin_amdgcn_s_barrier();                 // ... and everyone else's
+    asm volatile("" ::: "memory");
+    nxt = lds + lane * 16;                        // slab 0 is "the following slab" until it is opened
+#pragma unroll
+    for (int i = 0; i < kFragDepth; ++i) f[i] = load(nxt + i * kChunkBytes);
+    if constexpr (LAG > 0) {
+      if (wave >= NWAVES / 2) {                   // trailing half: sit out the first LAG slabs
+#pragma unroll 1
+        for (int i = 0; i < LAG; ++i) idle_slab();
+      }
+    }
+  }
+
+  // take part in a slab step (wait, barrier, DMA issue) without opening a slab
+  __device__ __forceinline__ void idle_slab() {
+    wait_vm<LPW>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // (3) refill the slot the previous slab occupied
     issue();
-    const char* p = lds + read_slot * kSlabBytes + lane * 16;
-    read_slot = (read_slot + 1 == kRingDepth) ? 0u : read_slot + 1;
-    return p;
+  }
+
+  // after the last tile: the leading half keeps the slab steps going until the trailing half is done
+  __device__ __forceinline__ void finish() {
+    if constexpr (LAG > 0) {
+      if (wave < NWAVES / 2) {
+#pragma unroll 1
+        for (int i = 0; i < LAG; ++i) idle_slab();
+      }
+    }
+    drain();
+  }
+
+  // Open the next slab: its first kFragDepth fragments are already in registers.
+  __device__ __forceinline__ void begin_slab() {
+    wait_vm<LPW>();                               // my pieces of the slab AFTER this one have landed
+    __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
+    asm volatile("" ::: "memory");
+    issue();                                      // refill the slot the previous slab occupied
+    cur = lds + read_slot * kSlabBytes + lane * 16;
+    read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
+    nxt = lds + read_slot * kSlabBytes + lane * 16;
   }
 
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 };
 
 // ---- one K-segment of a layer: acc[NBO] += W[:, segment] . in[NBLK] -----------------------------
-template <class M, int NBO, int NBLK, int NWAVES>
-__device__ __forceinline__ void consume(Ring<NWAVES>& ring, f32x16 (&acc)[NBO],
+template <class M, int NBO, int NBLK, class PipeT>
+__device__ __forceinline__ void consume(PipeT& pipe, f32x16 (&acc)[NBO],
                                         const typename M::Block (&in)[NBLK]) {
   constexpr int KPS = kSlabChunks / NBO;         // chunk rows (K steps) per slab
   constexpr int CHUNKS = NBLK * M::CPB;          // real chunk rows of this segment
   constexpr int SLABS = (CHUNKS + KPS - 1) / KPS;
   static_for<SLABS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
-    const char* p = ring.advance();
-    static_for<KPS>([&](auto kk_) {
-      constexpr int kk = decltype(kk_)::value;
+    constexpr int ROWS = (CHUNKS - s * KPS) < KPS ? (CHUNKS - s * KPS) : KPS;
+    constexpr int USED = ROWS * NBO;             // chunks of this slab that carry weights (a prefix)
+    static_assert(USED % kFragDepth == 0 && USED >= kFragDepth, "fragment pipeline needs USED % depth == 0");
+    pipe.begin_slab();
+    static_for<USED>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      constexpr int kk = p / NBO, nb = p % NBO;
       constexpr int kc = s * KPS + kk;
-      if constexpr (kc < CHUNKS) {
-        static_for<NBO>([&](auto nb_) {
-          constexpr int nb = decltype(nb_)::value;
-          M::template mma<kc % M::CPB>(acc[nb], p + (kk * NBO + nb) * kChunkBytes, in[kc / M::CPB]);
-        });
-      }
+      M::template mma<kc % M::CPB>(acc[nb], pipe.f[p % kFragDepth], in[kc / M::CPB]);
+      if constexpr (p + kFragDepth < USED)
+        pipe.f[p % kFragDepth] = pipe.load(pipe.cur + (p + kFragDepth) * kChunkBytes);
+      else
+        pipe.f[p % kFragDepth] = pipe.load(pipe.nxt + (p + kFragDepth - USED) * kChunkBytes);
     });
   });
 }
@@ -210,14 +284,18 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
   static_for<NBO>([&](auto nb_) {
     constexpr int nb = decltype(nb_)::value;
     float x[16];
+    // 16-bit operands: ReLU is applied AFTER packing as a signed 16-bit max with 0 on the pairs
+    // (sign-magnitude floats: negative <=> negative int16), half the VALU work of 16 v_max_f32
+    constexpr bool kPackedRelu = (ACT == kRelu) && (M::kElemBytes == 2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[nb][r];
-      if constexpr (ACT == kRelu) v = fmaxf(v, 0.0f);
+      if constexpr (ACT == kRelu && !kPackedRelu) v = fmaxf(v, 0.0f);
       if constexpr (ACT == kLeaky) v = v > 0.0f ? v : 0.01f * v;
       x[r] = v;
     }
     M::from_f32(out[nb], x);
+    if constexpr (kPackedRelu) M::relu_packed(out[nb]);
   });
 }
 

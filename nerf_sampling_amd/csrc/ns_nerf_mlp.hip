@@ -11,6 +11,8 @@ namespace {
 
 using namespace nsmlp;
 
+constexpr int kLag = 4;  // slabs the trailing half of an 8-wave workgroup runs behind (half a 256-wide layer)
+
 struct NerfArgs {
   const char* stream;
   const float* bias;
@@ -46,7 +48,7 @@ __device__ __forceinline__ void gather3(typename M::Block (&out)[NBLK], const fl
   });
 }
 
-template <class M, int NB, int NWAVES, bool PRECISE_TRIG, bool EMBEDDED>
+template <class M, int NB, int NWAVES, int LAG, bool PRECISE_TRIG, bool EMBEDDED>
 __global__ void __launch_bounds__(NWAVES * 64)
 nerf_mlp_kernel(NerfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,12 +57,13 @@ nerf_mlp_kernel(NerfArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5;
 
-  // LDS image: [ring: kRingDepth x 16 KiB][bias floats]
-  float* bias_lds = reinterpret_cast<float*>(smem + kRingDepth * kSlabBytes);
+  using PipeT = Pipe<M, NWAVES, LAG>;
+  // LDS image: [ring: PipeT::RING x 16 KiB][bias floats]
+  float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
   for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
   __syncthreads();
 
-  Ring<NWAVES> ring;
+  PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
 
   const int64_t n_tiles = (a.S + 31) / 32;
@@ -99,41 +102,41 @@ nerf_mlp_kernel(NerfArgs a) {
     Block hcur[NB];
     // layer 0
     init_bias<NB>(acc, bias, h); bias += NB * 32;
-    consume<M, NB, 2, NWAVES>(ring, acc, xe);
+    consume<M, NB, 2>(ring, acc, xe);
     to_blocks<M, kRelu, NB>(hcur, acc);
     // layers 1 .. D-1 (the layer after `skip` sees cat[x, h])
     for (int l = 1; l < a.D; ++l) {
       init_bias<NB>(acc, bias, h); bias += NB * 32;
-      if (l - 1 == a.skip) consume<M, NB, 2, NWAVES>(ring, acc, xe);
-      consume<M, NB, NB, NWAVES>(ring, acc, hcur);
+      if (l - 1 == a.skip) consume<M, NB, 2>(ring, acc, xe);
+      consume<M, NB, NB>(ring, acc, hcur);
       to_blocks<M, kRelu, NB>(hcur, acc);
     }
     // sigma head (W -> 1): row 0 of a 32-row block
     f32x16 acc1[1];
     init_bias<1>(acc1, bias, h); bias += 32;
-    consume<M, 1, NB, NWAVES>(ring, acc1, hcur);
+    consume<M, 1, NB>(ring, acc1, hcur);
     const float sigma = acc1[0][0];
     // feature (W -> W, no activation)
     init_bias<NB>(acc, bias, h); bias += NB * 32;
-    consume<M, NB, NB, NWAVES>(ring, acc, hcur);
+    consume<M, NB, NB>(ring, acc, hcur);
     to_blocks<M, kNone, NB>(hcur, acc);
     // views: cat[feature, dirs27] -> W/2, relu
     f32x16 accv[NB / 2];
     Block hv[NB / 2];
     init_bias<NB / 2>(accv, bias, h); bias += (NB / 2) * 32;
-    consume<M, NB / 2, NB, NWAVES>(ring, accv, hcur);
-    consume<M, NB / 2, 1, NWAVES>(ring, accv, ve);
+    consume<M, NB / 2, NB>(ring, accv, hcur);
+    consume<M, NB / 2, 1>(ring, accv, ve);
     to_blocks<M, kRelu, NB / 2>(hv, accv);
     // rgb (W/2 -> 3): rows 0..2
     init_bias<1>(acc1, bias, h);
-    consume<M, 1, NB / 2, NWAVES>(ring, acc1, hv);
+    consume<M, 1, NB / 2>(ring, acc1, hv);
 
     if (valid && h == 0) {
       float4 o4 = make_float4(acc1[0][0], acc1[0][1], acc1[0][2], sigma);
       reinterpret_cast<float4*>(a.raw)[s] = o4;
     }
   }
-  ring.drain();
+  ring.finish();
 }
 
 // number of slabs one pass of the program consumes (must equal ns_weights::n_slabs)
@@ -148,10 +151,10 @@ int nerf_program_slabs(int cpb, int NB, int D, int skip) {
   return n;
 }
 
-template <class M, int NB, int NWAVES, bool PRECISE, bool EMB>
+template <class M, int NB, int NWAVES, int LAG, bool PRECISE, bool EMB>
 int launch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
-  const size_t lds = static_cast<size_t>(kRingDepth) * kSlabBytes + static_cast<size_t>(a.bias_floats) * 4;
-  auto kern = nerf_mlp_kernel<M, NB, NWAVES, PRECISE, EMB>;
+  const size_t lds = static_cast<size_t>(Pipe<M, NWAVES, LAG>::kLdsBytes) + static_cast<size_t>(a.bias_floats) * 4;
+  auto kern = nerf_mlp_kernel<M, NB, NWAVES, LAG, PRECISE, EMB>;
   static bool attr_set = false;
   if (!attr_set) {
     NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -180,11 +183,11 @@ int dispatch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
   }
   switch (net->dtype) {
     case NS_DTYPE_F32:
-      return NB == 8 ? launch<MmaF32, 8, 4, true, EMB>(net, a, stream) : launch<MmaF32, 4, 4, true, EMB>(net, a, stream);
+      return NB == 8 ? launch<MmaF32, 8, 4, 0, true, EMB>(net, a, stream) : launch<MmaF32, 4, 4, 0, true, EMB>(net, a, stream);
     case NS_DTYPE_BF16:
-      return NB == 8 ? launch<MmaBF16, 8, EMB ? 4 : 8, false, EMB>(net, a, stream) : launch<MmaBF16, 4, 8, false, EMB>(net, a, stream);
+      return NB == 8 ? launch<MmaBF16, 8, EMB ? 4 : 8, EMB ? 0 : kLag, false, EMB>(net, a, stream) : launch<MmaBF16, 4, 8, kLag, false, EMB>(net, a, stream);
     case NS_DTYPE_F16:
-      return NB == 8 ? launch<MmaF16, 8, EMB ? 4 : 8, false, EMB>(net, a, stream) : launch<MmaF16, 4, 8, false, EMB>(net, a, stream);
+      return NB == 8 ? launch<MmaF16, 8, EMB ? 4 : 8, EMB ? 0 : kLag, false, EMB>(net, a, stream) : launch<MmaF16, 4, 8, kLag, false, EMB>(net, a, stream);
   }
   return NS_E_UNSUPPORTED;
 }
