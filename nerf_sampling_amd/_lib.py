@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_sampling_hip.so")
+LIB_PATH = os.environ.get("NS_LIB_PATH") or os.path.join(_HERE, "libnerf_sampling_hip.so")
 
 NS_OK = 0
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2

@@ -156,8 +156,9 @@ struct Pipe {
   uint32_t issue_slot;
   uint32_t read_slot;   // slot of the slab the next begin_slab() opens
   int wave, lane;
-  const char* cur;      // this lane's read pointer into the open slab (chunk c at +c*1024)
-  const char* nxt;      // ... and into the following one
+  uint32_t lds_off;     // LDS byte address of the ring base
+  uint32_t cur;         // this lane's LDS byte address in the open slab (chunk c at +c*1024)
+  uint32_t nxt;         // ... and in the following one
   AFrag f[kFragDepth];  // fragments of the next kFragDepth chunks
 
   __device__ __forceinline__ void issue() {
@@ -173,16 +174,23 @@ struct Pipe {
     issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
   }
 
+  // s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields at their maxima = "don't wait"); gfx9 encoding:
+  // vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14.  The builtin (not inline asm) keeps
+  // the compiler's own counter bookkeeping exact, so its LDS waits stay counted (lgkmcnt(N > 0)).
   template <int N>
   __device__ static __forceinline__ void wait_vm() {
-    static_assert(N == 0 || N == 2 || N == 4 || N == 8, "unexpected DMA count");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 0 && N < 16, "unexpected DMA count");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | N);
   }
 
-  __device__ __forceinline__ AFrag load(const char* p) const { return *reinterpret_cast<const AFrag*>(p); }
+  // A-fragment read: a plain LDS load (ds_read_b128 from a lane-linear image, conflict-free).  Measured
+  // alternative (round 1): inline-asm reads with hand-counted lgkmcnt(3) instead of the compiler's
+  // lgkmcnt(0) every fourth MFMA -- same kernel time (35.4 vs 35.2 ms), so the compiler-visible form stays.
+  template <int OFF>
+  __device__ __forceinline__ void load(AFrag& dst, uint32_t addr) const {
+    dst = *reinterpret_cast<const AFrag __attribute__((address_space(3)))*>(static_cast<uintptr_t>(addr + OFF));
+  }
+  __device__ static __forceinline__ void wait_frag(AFrag&) {}
 
   __device__ __forceinline__ void init(const char* stream_, char* lds_, uint32_t n_slabs_, int wave_, int lane_) {
     stream = stream_; lds = lds_; n_slabs = n_slabs_; wave = wave_; lane = lane_;
@@ -191,9 +199,10 @@ struct Pipe {
     wait_vm<2 * LPW>();                           // my pieces of slab 0 have landed ...
     __builtin_amdgcn_s_barrier();                 // ... and everyone else's
     asm volatile("" ::: "memory");
-    nxt = lds + lane * 16;                        // slab 0 is "the following slab" until it is opened
-#pragma unroll
-    for (int i = 0; i < kFragDepth; ++i) f[i] = load(nxt + i * kChunkBytes);
+    lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
+    nxt = lds_off + lane * 16;                    // slab 0 is "the following slab" until it is opened
+    cur = nxt;
+    static_for<kFragDepth>([&](auto i_) { load<decltype(i_)::value * kChunkBytes>(f[decltype(i_)::value], nxt); });
     if constexpr (LAG > 0) {
       if (wave >= NWAVES / 2) {                   // trailing half: sit out the first LAG slabs
 #pragma unroll 1
@@ -224,12 +233,16 @@ struct Pipe {
   // Open the next slab: its first kFragDepth fragments are already in registers.
   __device__ __forceinline__ void begin_slab() {
     wait_vm<LPW>();                               // my pieces of the slab AFTER this one have landed
+#ifndef NS_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
+#endif
     asm volatile("" ::: "memory");
+#ifndef NS_ABLATE_DMA
     issue();                                      // refill the slot the previous slab occupied
-    cur = lds + read_slot * kSlabBytes + lane * 16;
+#endif
+    cur = lds_off + read_slot * kSlabBytes + lane * 16;
     read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
-    nxt = lds + read_slot * kSlabBytes + lane * 16;
+    nxt = lds_off + read_slot * kSlabBytes + lane * 16;
   }
 
   __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
@@ -252,11 +265,12 @@ __device__ __forceinline__ void consume(PipeT& pipe, f32x16 (&acc)[NBO],
       constexpr int p = decltype(p_)::value;
       constexpr int kk = p / NBO, nb = p % NBO;
       constexpr int kc = s * KPS + kk;
+      PipeT::wait_frag(pipe.f[p % kFragDepth]);
       M::template mma<kc % M::CPB>(acc[nb], pipe.f[p % kFragDepth], in[kc / M::CPB]);
       if constexpr (p + kFragDepth < USED)
-        pipe.f[p % kFragDepth] = pipe.load(pipe.cur + (p + kFragDepth) * kChunkBytes);
+        pipe.template load<(p + kFragDepth) * kChunkBytes>(pipe.f[p % kFragDepth], pipe.cur);
       else
-        pipe.f[p % kFragDepth] = pipe.load(pipe.nxt + (p + kFragDepth - USED) * kChunkBytes);
+        pipe.template load<(p + kFragDepth - USED) * kChunkBytes>(pipe.f[p % kFragDepth], pipe.nxt);
     });
   });
 }
@@ -287,6 +301,9 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
     // 16-bit operands: ReLU is applied AFTER packing as a signed 16-bit max with 0 on the pairs
     // (sign-magnitude floats: negative <=> negative int16), half the VALU work of 16 v_max_f32
     constexpr bool kPackedRelu = (ACT == kRelu) && (M::kElemBytes == 2);
+#ifdef NS_ABLATE_EPILOGUE
+    if (nb > 0) return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[nb][r];
