@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--scene", default="lego_synth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=50, help="rows of the frame timed on the CPU (x 800 rays)")
+    ap.add_argument("--mode", default="depthnet", choices=["depthnet", "full_nerf"],
+                    help="depthnet = BASELINE configs[1] (headline); full_nerf = configs[2], vanilla 64+128 coarse+fine")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a one-GPU box, all ranks sharing cuda:0)")
     args = ap.parse_args()
@@ -125,8 +127,28 @@ def main():
     fine, dn, params = build_modules(args.scene, device)
     nerf_w, depth_w = fine.packed(args.dtype), dn.packed(args.dtype)
     events = []
-    renderer = FrameRenderer(H, W, hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1,
-                                                    device=device, events=events), device)
+    if args.mode == "depthnet":
+        rows_fn = hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1, device=device, events=events)
+        samples_in_timed_kernel = args.samples
+    else:
+        from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+        cfg = synthetic.SCENES[args.scene]["coarse"]
+        coarse = NeRF(D=cfg["D"], W=cfg["W"], input_ch=63, input_ch_views=27, output_ch=5, skips=[4], use_viewdirs=True)
+        coarse.load_state_dict(params["coarse"])
+        coarse_w = coarse.to(device).packed(args.dtype)
+        ws = ops.RenderWorkspace()
+
+        def rows_fn(c2w, row0, row1):
+            ev = (ops.Event(), ops.Event())
+            events.append(ev)
+            out = ops.render_rays_hierarchical(coarse_w, nerf_w, camera=(H, W, K, c2w, row0, row1), n_coarse=64,
+                                               n_importance=128, lindisp=True, white_bkgd=True, workspace=ws,
+                                               device=device, mlp_events=ev)
+            return out["rgb"], out["disp"]
+
+        samples_in_timed_kernel = 192  # the fine pass (64 + 128 samples) is the event-timed launch
+    renderer = FrameRenderer(H, W, rows_fn, device)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -152,14 +174,15 @@ def main():
     # dominant kernel (NeRF MLP), timed with HIP events on its own stream inside the timed region
     mlp_ms = float(np.mean([b.elapsed_ms(e) for b, e in events])) if events else float("nan")
     rays_per_launch = renderer.rays_per_rank
-    mlp_flop = rays_per_launch * args.samples * NERF_FLOP_PER_SAMPLE
+    mlp_flop = rays_per_launch * samples_in_timed_kernel * NERF_FLOP_PER_SAMPLE
     achieved = mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else float("nan")
     peak = PEAK_TFLOPS[args.dtype]
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (not live);
     # only quoted for the exact workload they were collected on
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic_nerf_mlp.json")
-    if world == 1 and args.dtype == "bf16" and args.size == 800 and args.samples == 64 and os.path.exists(tpath):
+    if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
+            and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
 
     if rank == 0:
@@ -169,16 +192,18 @@ def main():
             "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "
-                                   f"(std 0.1) through the NeRF 8x256 fine MLP, seeded synthetic weights ({args.scene}), "
-                                   "spiral render poses of load_blender.py",
+            "config": {"workload": (f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "
+                                    f"(std 0.1) through the NeRF 8x256 fine MLP" if args.mode == "depthnet" else
+                                    f"Lego-shaped {H}x{W} frame, vanilla hierarchical 64 coarse + 128 importance "
+                                    f"samples/ray (coarse + fine NeRF 8x256)")
+                                   + f", seeded synthetic weights ({args.scene}), spiral render poses of load_blender.py",
                        "rays_per_step": H * W, "samples_per_ray": args.samples,
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
             "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "depthnet":
             mid = H // 2
             rows = (mid - args.cpu_rows // 2, mid - args.cpu_rows // 2 + args.cpu_rows)
             out["cpu_baseline"] = cpu_baseline(params, H, W, K, poses[args.warmup % 40], args.samples, rows)

@@ -179,6 +179,38 @@ typedef struct ns_render_args {
 int64_t ns_render_workspace_bytes(int64_t R, int N);
 int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
 
+/* ---- a11 as one call: sample_as_in_NeRF (nerf_utils.py:497-611) = coarse pass, inverse-CDF importance
+ * sampling, sorted merge, fine pass.  Rays explicit or generated from the camera (o_dev == NULL).
+ * Outputs of the FINE pass: rgb [R,3], disp [R] always; z / weights [R,Nc+Nf] and raw [R,Nc+Nf,4] if
+ * non-NULL.  t_rand [R,Nc] (stratified jitter) and u [R,Nf] (inverse-CDF draws) are NULL for the
+ * deterministic perturb == 0 path.                                                               */
+typedef struct ns_hier_args {
+  const ns_weights* coarse;
+  const ns_weights* fine; /* NULL: the coarse network is used for both passes */
+  const float* o_dev;
+  const float* d_dev;
+  const float* viewdirs_dev;
+  int64_t R;
+  int H, W, row0, row1;
+  float fx, fy, cx, cy;
+  float c2w[12];
+  int Nc, Nf;
+  int lindisp, white_bkgd;
+  float near_, far_;
+  const float* t_rand_dev;
+  const float* u_dev;
+  void* workspace_dev; /* ns_hier_workspace_bytes(R, Nc, Nf) bytes, 256-byte aligned */
+  float* rgb_dev;
+  float* disp_dev;
+  float* z_dev;
+  float* weights_dev;
+  float* raw_dev;
+  void* ev_mlp_begin; /* optional hipEvent_t pair around the FINE-pass MLP kernel */
+  void* ev_mlp_end;
+} ns_hier_args;
+int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf);
+int ns_render_rays_hierarchical(const ns_hier_args* args, void* stream);
+
 /* ---- timing helpers (hipEvent_t as void*) used by bench.py for the live roofline figure --------- */
 int ns_event_create(void** ev);
 void ns_event_destroy(void* ev);

@@ -40,6 +40,22 @@ class RenderArgs(C.Structure):
     ]
 
 
+class HierArgs(C.Structure):
+    """struct ns_hier_args"""
+
+    _fields_ = [
+        ("coarse", _p), ("fine", _p),
+        ("o_dev", _p), ("d_dev", _p), ("viewdirs_dev", _p), ("R", _i64),
+        ("H", _i), ("W", _i), ("row0", _i), ("row1", _i),
+        ("fx", _f), ("fy", _f), ("cx", _f), ("cy", _f),
+        ("c2w", _f * 12),
+        ("Nc", _i), ("Nf", _i), ("lindisp", _i), ("white_bkgd", _i), ("near_", _f), ("far_", _f),
+        ("t_rand_dev", _p), ("u_dev", _p), ("workspace_dev", _p),
+        ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("raw_dev", _p),
+        ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/nerf_sampling_hip.h declares
 SIGNATURES = {
     "ns_last_error": (C.c_char_p, []),
@@ -66,6 +82,8 @@ SIGNATURES = {
     "ns_argmax_gather": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ns_render_workspace_bytes": (_i64, [_i64, _i]),
     "ns_render_rays_depthnet": (_i, [C.POINTER(RenderArgs), _p]),
+    "ns_hier_workspace_bytes": (_i64, [_i64, _i, _i]),
+    "ns_render_rays_hierarchical": (_i, [C.POINTER(HierArgs), _p]),
     "ns_event_create": (_i, [C.POINTER(_p)]),
     "ns_event_destroy": (None, [_p]),
     "ns_event_record": (_i, [_p, _p]),

@@ -29,6 +29,10 @@ int cu_count();
 
 }  // namespace ns
 
+// internal (not part of the public header)
+extern "C" int ns_coarse_z_scalar(float near_, float far_, int64_t R, int N, int lindisp, const float* t_rand_dev,
+                                  float* z_dev, void* stream);
+
 #define NS_REQUIRE(cond, msg)                    \
   do {                                           \
     if (!(cond)) {                               \

@@ -167,14 +167,14 @@ points_kernel(const float* __restrict__ o, const float* __restrict__ d,
 
 // a11: Trainer.py:603-626
 __global__ void __launch_bounds__(kBlock)
-coarse_z_kernel(const float* __restrict__ near_, const float* __restrict__ far_, int64_t R, int N,
-                int lindisp, const float* __restrict__ t_rand, float* __restrict__ z) {
+coarse_z_kernel(const float* __restrict__ near_, const float* __restrict__ far_, float near_s, float far_s,
+                int64_t R, int N, int lindisp, const float* __restrict__ t_rand, float* __restrict__ z) {
   const int64_t total = R * N;
   for (int64_t e = blockIdx.x * (int64_t)kBlock + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * kBlock) {
     const int64_t r = e / N;
     const int i = static_cast<int>(e % N);
-    const float nr = near_[r], fr = far_[r];
+    const float nr = near_ ? near_[r] : near_s, fr = far_ ? far_[r] : far_s;
     auto zval = [&](int k) {
       const float t = linspace_at(0.0f, 1.0f, N, k);
       return lindisp ? 1.0f / (1.0f / nr * (1.0f - t) + 1.0f / fr * t) : nr * (1.0f - t) + fr * t;
@@ -332,7 +332,19 @@ int ns_coarse_z(const float* near_dev, const float* far_dev, int64_t R, int N, i
   NS_REQUIRE(R >= 0 && N >= 1, "bad shape");
   if (R == 0) return NS_OK;
   NS_REQUIRE(near_dev && far_dev && z_dev, "null pointer");
-  coarse_z_kernel<<<ns::ew_grid(R * N, kBlock), kBlock, 0, ns::as_stream(stream)>>>(near_dev, far_dev, R, N,
+  coarse_z_kernel<<<ns::ew_grid(R * N, kBlock), kBlock, 0, ns::as_stream(stream)>>>(near_dev, far_dev, 0.f, 0.f, R, N,
+                                                                                   lindisp, t_rand_dev, z_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+// same with one near / far for every ray (used by ns_render_rays_hierarchical)
+int ns_coarse_z_scalar(float near_, float far_, int64_t R, int N, int lindisp, const float* t_rand_dev,
+                       float* z_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 1, "bad shape");
+  if (R == 0) return NS_OK;
+  NS_REQUIRE(z_dev, "null pointer");
+  coarse_z_kernel<<<ns::ew_grid(R * N, kBlock), kBlock, 0, ns::as_stream(stream)>>>(nullptr, nullptr, near_, far_, R, N,
                                                                                    lindisp, t_rand_dev, z_dev);
   NS_LAUNCH_CHECK();
   return NS_OK;

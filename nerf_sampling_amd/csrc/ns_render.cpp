@@ -78,6 +78,67 @@ int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
                         a->weights_dev, stream);
 }
 
+int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf) {
+  if (R < 0 || Nc < 3 || Nf < 0) return 0;
+  const int64_t Nt = Nc + Nf;
+  // o, d, view | z_c [R,Nc] | raw_c [R,Nc,4] | w_c [R,Nc] | z_f [R,Nt] | raw_f [R,Nt,4]
+  return 3 * align256(R * 12) + align256(R * Nc * 4) + align256(R * Nc * 16) + align256(R * Nc * 4) +
+         align256(R * Nt * 4) + align256(R * Nt * 16);
+}
+
+int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
+  NS_REQUIRE(a && a->coarse, "null args / coarse network");
+  NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
+  NS_REQUIRE(a->Nc >= 3 && a->Nf >= 0, "needs at least 3 coarse samples");
+  int64_t R = a->R;
+  if (!a->o_dev) {
+    NS_REQUIRE(a->row0 >= 0 && a->row1 <= a->H && a->row0 <= a->row1 && a->W > 0, "bad camera rows");
+    R = static_cast<int64_t>(a->row1 - a->row0) * a->W;
+  } else {
+    NS_REQUIRE(a->d_dev && a->viewdirs_dev, "explicit rays need o, d and viewdirs");
+  }
+  if (R == 0) return NS_OK;
+  char* ws = static_cast<char*>(a->workspace_dev);
+  NS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be 256-byte aligned");
+  const int Nc = a->Nc, Nt = a->Nc + a->Nf;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = ws + off; off += align256(bytes); return reinterpret_cast<float*>(p); };
+  float* wo = take(R * 12); float* wd = take(R * 12); float* wv = take(R * 12);
+  float* z_c = take(R * Nc * 4); float* raw_c = take(R * Nc * 16); float* w_c = take(R * Nc * 4);
+  float* z_f_ws = take(R * Nt * 4); float* raw_f_ws = take(R * Nt * 16);
+  const float* o = a->o_dev; const float* d = a->d_dev; const float* view = a->viewdirs_dev;
+  int rc;
+  if (!o) {
+    rc = ns_get_rays(a->H, a->W, a->fx, a->fy, a->cx, a->cy, a->c2w, a->row0, a->row1, a->near_, a->far_, wo, wd, wv,
+                     nullptr, stream);
+    if (rc != NS_OK) return rc;
+    o = wo; d = wd; view = wv;
+  }
+  // coarse pass (Trainer.py:579-649); its rgb/disp are not part of the 8-tuple and are not produced
+  rc = ns_coarse_z_scalar(a->near_, a->far_, R, Nc, a->lindisp, a->t_rand_dev, z_c, stream);
+  if (rc != NS_OK) return rc;
+  rc = ns_nerf_forward(a->coarse, nullptr, o, d, z_c, view, R, Nc, raw_c, stream);
+  if (rc != NS_OK) return rc;
+  rc = ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, w_c,
+                      stream);
+  if (rc != NS_OK) return rc;
+  if (a->Nf == 0) {  // no importance samples: the coarse pass is the result
+    return ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr,
+                          nullptr, a->weights_dev, stream);
+  }
+  // fine pass (Trainer.py:651-710)
+  float* z_f = a->z_dev ? a->z_dev : z_f_ws;
+  float* raw_f = a->raw_dev ? a->raw_dev : raw_f_ws;
+  rc = ns_importance_z(z_c, w_c, R, Nc, a->Nf, a->u_dev, z_f, stream);
+  if (rc != NS_OK) return rc;
+  if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
+  rc = ns_nerf_forward(a->fine ? a->fine : a->coarse, nullptr, o, d, z_f, view, R, Nt, raw_f, stream);
+  if (rc != NS_OK) return rc;
+  if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
+  return ns_raw2outputs(raw_f, z_f, d, nullptr, R, Nt, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr, nullptr,
+                        a->weights_dev, stream);
+}
+
 int ns_event_create(void** ev) {
   NS_REQUIRE(ev, "null pointer");
   hipEvent_t e;

@@ -404,6 +404,58 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     return out
 
 
+def render_rays_hierarchical(coarse: PackedWeights, fine: Optional[PackedWeights], *, rays=None, camera=None,
+                             n_coarse: int = 64, n_importance: int = 128, lindisp: bool = True,
+                             white_bkgd: bool = True, near: float = 2.0, far: float = 6.0,
+                             t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None, extras: bool = False,
+                             workspace: Optional[RenderWorkspace] = None, device="cuda", mlp_events=None):
+    """Vanilla coarse + fine pass (sample_as_in_NeRF) as one C call; returns the FINE pass outputs."""
+    lib = _lib.load()
+    a = _lib.HierArgs()
+    a.coarse = coarse.handle
+    a.fine = fine.handle if fine is not None else None
+    keep = []
+    if rays is not None:
+        o, d, v = (_dev(t, n) for t, n in zip(rays, ("rays_o", "rays_d", "viewdirs")))
+        keep += [o, d, v]
+        device = o.device
+        R = o.shape[0]
+        a.o_dev, a.d_dev, a.viewdirs_dev, a.R = o.data_ptr(), d.data_ptr(), v.data_ptr(), R
+    else:
+        H, W, K, c2w, row0, row1 = camera
+        c2w_h = (c2w.detach().cpu().numpy() if isinstance(c2w, Tensor) else np.asarray(c2w)).astype(np.float32)[:3, :4]
+        a.H, a.W, a.row0, a.row1 = H, W, row0, row1
+        a.fx, a.fy, a.cx, a.cy = float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2])
+        for i, val in enumerate(c2w_h.reshape(-1)):
+            a.c2w[i] = float(val)
+        R = (row1 - row0) * W
+        a.R = R
+    device = torch.device(device)
+    a.Nc, a.Nf, a.lindisp, a.white_bkgd = int(n_coarse), int(n_importance), int(bool(lindisp)), int(bool(white_bkgd))
+    a.near_, a.far_ = float(near), float(far)
+    for name, t in (("t_rand_dev", t_rand), ("u_dev", u)):
+        if t is not None:
+            t = _dev(t, name)
+            keep.append(t)
+            setattr(a, name, t.data_ptr())
+    nbytes = int(lib.ns_hier_workspace_bytes(R, a.Nc, a.Nf))
+    ws = (workspace or _default_ws).get(nbytes, device)
+    a.workspace_dev = (ws.data_ptr() + 255) & ~255
+    Nt = a.Nc + a.Nf
+    out = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=device),
+           "disp": torch.empty((R,), dtype=torch.float32, device=device)}
+    a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
+    if extras:
+        out["z"] = torch.empty((R, Nt), dtype=torch.float32, device=device)
+        out["weights"] = torch.empty((R, Nt), dtype=torch.float32, device=device)
+        out["raw"] = torch.empty((R, Nt, 4), dtype=torch.float32, device=device)
+        a.z_dev, a.weights_dev, a.raw_dev = out["z"].data_ptr(), out["weights"].data_ptr(), out["raw"].data_ptr()
+    if mlp_events is not None:
+        a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
+    check(lib.ns_render_rays_hierarchical(C.byref(a), _stream(device)), "ns_render_rays_hierarchical")
+    return out
+
+
 class Event:
     """hipEvent wrapper for timing a kernel on the stream it is launched on."""
 

@@ -279,3 +279,80 @@ def test_full_size_frame_properties(gpu_modules, dtype, min_psnr):
     print(f"{dtype}: PSNR vs fp32 path on rows {band} = {psnr:.2f} dB, median |rgb err| = {med:.2e}")
     assert psnr > min_psnr
     assert med < (2e-3 if dtype == "bf16" else 3e-4)
+
+
+def test_fused_hierarchical_matches_operator_chain(golden, gpu_modules):
+    """ns_render_rays_hierarchical (one C call) == sample_as_in_NeRF through the mirrored operators,
+    and matches the reference golden within the hierarchical-path conditioning."""
+    from nerf_sampling_amd import nerf_utils, ops
+
+    g = golden("hierarchical")
+    m = gpu_modules("tiny_synth")
+    rb = T(g["ray_batch"]).cuda()
+    for lindisp in (True, False):
+        tr = make_trainer(lindisp=lindisp)
+        kw = render_kwargs(tr, m)
+        chain = nerf_utils.sample_as_in_NeRF(ray_batch=rb, network_fn=kw["network_fn"], network_fine=kw["network_fine"],
+                                             network_query_fn=kw["network_query_fn"], N_samples=64, trainer=tr,
+                                             perturb=0.0, raw_noise_std=0.0, lindisp=lindisp, white_bkgd=True,
+                                             kwargs={}, pytest=False)
+        fused = ops.render_rays_hierarchical(m["coarse"].packed("f32"), m["fine"].packed("f32"),
+                                             rays=(rb[:, 0:3], rb[:, 3:6], rb[:, 8:11]), n_coarse=64, n_importance=128,
+                                             lindisp=lindisp, white_bkgd=True, extras=True)
+        assert torch.equal(fused["z"], chain[1]) and torch.equal(fused["rgb"], chain[3])
+        assert torch.equal(fused["weights"], chain[4]) and torch.equal(fused["raw"], chain[7])
+        exp = g[f"tiny_synth_lin{int(lindisp)}_rgb_map"]
+        bad, err = frac_bad(npy(fused["rgb"]), exp, 2e-4)
+        assert bad <= 0.03 and np.median(err) < 5e-5
+    # stratified jitter + random inverse-CDF draws injected (perturb = 1 of the reference, seeded)
+    fused = ops.render_rays_hierarchical(m["coarse"].packed("f32"), m["fine"].packed("f32"),
+                                         rays=(rb[:, 0:3], rb[:, 3:6], rb[:, 8:11]), n_coarse=64, n_importance=128,
+                                         lindisp=True, white_bkgd=True, t_rand=T(g["perturb_t_rand"]).cuda(),
+                                         u=T(g["perturb_u"]).cuda(), extras=True)
+    bad, err = frac_bad(npy(fused["z"]), g["perturb_z"], 5e-3)
+    assert bad <= 0.03
+    bad, err = frac_bad(npy(fused["rgb"]), g["perturb_rgb_map"], 2e-4)
+    assert bad <= 0.03 and np.median(err) < 5e-5
+
+
+def test_full_size_hierarchical_config3(gpu_modules):
+    """BASELINE config 3 size: 800x800, vanilla 64 + 128 samples/ray (coarse + fine MLP), bf16."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("lego_synth")
+    H = W = 800
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(99.0, -30.0, 4.0)[:3, :4]
+    out = ops.render_rays_hierarchical(m["coarse"].packed("bf16"), m["fine"].packed("bf16"), camera=(H, W, K, c2w, 0, H),
+                                       n_coarse=64, n_importance=128, lindisp=True, white_bkgd=True, extras=True)
+    rgb, w, z = out["rgb"], out["weights"], out["z"]
+    assert rgb.shape == (H * W, 3) and z.shape == (H * W, 192) and torch.isfinite(rgb).all()
+    assert float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1 + 1e-5
+    assert (z[:, 1:] >= z[:, :-1]).all() and float(z.min()) >= 2.0 - 1e-5 and float(z.max()) <= 6.0 + 1e-5
+    assert (w >= 0).all() and float(w.sum(-1).max()) <= 1 + 1e-4
+    half = ops.render_rays_hierarchical(m["coarse"].packed("bf16"), m["fine"].packed("bf16"),
+                                        camera=(H, W, K, c2w, 400, 800), n_coarse=64, n_importance=128, lindisp=True)
+    assert torch.equal(half["rgb"], rgb[400 * W :])
+
+
+def test_full_size_config5_fp16(gpu_modules):
+    """BASELINE config 5 size: 1600x1600, DepthNet + 192 samples/ray, fp16 MFMA (one GPU's 200-row shard of 8)."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("lego_synth")
+    H = W = 1600
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(-135.0, -30.0, 4.0)[:3, :4]
+    out = ops.render_rays_depthnet(m["depth"].packed("f16"), m["fine"].packed("f16"), camera=(H, W, K, c2w, 600, 800),
+                                   n_samples=192, mode="uniform", std=0.1, extras=True)
+    rgb, w, z = out["rgb"], out["weights"], out["z"]
+    assert rgb.shape == (200 * W, 3) and z.shape == (200 * W, 192) and torch.isfinite(rgb).all()
+    assert (z[:, 1:] >= z[:, :-1]).all() and float(z.min()) >= 2.0 and float(z.max()) <= 6.0
+    assert (w >= 0).all() and float(w.sum(-1).max()) <= 1 + 1e-4
+    # gaussian placement at the same size: sorted, contains the mean, injected noise honoured
+    noise = torch.randn(200 * W, 191, device="cuda")
+    g1 = ops.render_rays_depthnet(m["depth"].packed("f16"), m["fine"].packed("f16"), camera=(H, W, K, c2w, 600, 800),
+                                  n_samples=192, mode="gaussian", std=0.1, noise=noise, extras=True)
+    g2 = ops.render_rays_depthnet(m["depth"].packed("f16"), m["fine"].packed("f16"), camera=(H, W, K, c2w, 600, 800),
+                                  n_samples=192, mode="gaussian", std=0.1, noise=noise, extras=True)
+    assert torch.equal(g1["rgb"], g2["rgb"]) and (g1["z"][:, 1:] >= g1["z"][:, :-1]).all()
