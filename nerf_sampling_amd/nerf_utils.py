@@ -100,6 +100,55 @@ def render_test(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0.
                    **kwargs)
 
 
+def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=False, save_scene_data=False,
+                gt_imgs=None, savedir=None, render_factor=0):
+    """Per-image loop with PSNR / PNG / psnr.txt / scene_data.pt outputs in the reference's format
+    (nerf_utils.py:258-360).  wandb logging is out of scope; PNGs are written with PIL."""
+    import numpy as np
+
+    H, W, focal = hwf
+    if render_factor != 0:
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    if wandb_log:
+        raise NotImplementedError("wandb logging is out of scope")
+    rgbs, disps, all_pts, all_weights = [], [], [], []
+    total_psnr, total_mse, psnr_info = 0, 0, None
+    n_render_poses = render_poses.shape[0]
+    for i, c2w in enumerate(render_poses):
+        rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        rgbs.append(rgb.cpu().numpy())
+        disps.append(disp.cpu().numpy())
+        if gt_imgs is not None and render_factor == 0:
+            psnr = -10.0 * np.log10(np.mean(np.square(rgbs[-1] - np.asarray(gt_imgs[i]))))
+            psnr_info = f"{i:03d}.png, PSNR: {psnr}"
+            if render_kwargs["trainer"].compare_nerf and extras.get("max_z_vals") is not None:
+                mse = torch.nn.functional.mse_loss(extras["max_z_vals"], extras["depth_net_z_vals"])
+                total_mse += mse
+                psnr_info += f", MSE: {mse}"
+            total_psnr += psnr
+        if savedir is not None:
+            from PIL import Image
+
+            Image.fromarray(run_nerf_helpers.to8b(rgbs[-1])).save(os.path.join(savedir, "{:03d}.png".format(i)))
+            if psnr_info is not None:
+                f = os.path.join(savedir, "psnr.txt")
+                with open(f, "a") as file:
+                    file.write(f"{psnr_info}\n")
+                if i == n_render_poses - 1:
+                    to_write = f"Avg of {n_render_poses} images:\nPSNR: {total_psnr/n_render_poses}\n"
+                    if total_mse > 0:
+                        to_write += f"MSE: {total_mse/n_render_poses}"
+                    with open(f, "a") as file:
+                        file.write(to_write)
+            if save_scene_data:
+                all_pts.append(torch.flatten(extras["depth_net_pts"], end_dim=2))
+                all_weights.append(torch.flatten(extras["depth_net_weights"], end_dim=2))
+    if save_scene_data and savedir is not None:
+        torch.save({"all_pts": torch.cat(all_pts), "all_weights": torch.cat(all_weights)},
+                   os.path.join(savedir, "scene_data.pt"))
+    return np.stack(rgbs, 0), np.stack(disps, 0), total_psnr / n_render_poses
+
+
 def create_nerf(args, model):
     """(render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer) -- nerf_utils.py:393-494."""
     embed_fn, input_ch = run_nerf_helpers.get_embedder(args.multires, args.i_embed, args.input_dims_embed)

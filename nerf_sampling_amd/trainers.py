@@ -121,10 +121,42 @@ class Trainer:
         return (rgb_map_0, disp_map_0, acc_map_0, rgb_map, disp_map, acc_map, raw, z_vals, pts, density, alphas,
                 weights)
 
+    def load_data(self):
+        raise NotImplementedError("only the Blender loader is provided (trainers.BlenderTrainer)")
+
+    def render(self, render_test, save_scene_data, images, i_test, render_poses, hwf, render_kwargs_test):
+        """renderonly_{test|path}_{step:06d}/ with NNN.png, psnr.txt[, scene_data.pt] -- Trainer.py:181-230
+        (the mp4 of the reference needs imageio-ffmpeg and is not written)."""
+        with torch.no_grad():
+            images = images[i_test] if render_test else None
+            testsavedir = os.path.join(self.basedir, self.expname, "renderonly_{}_{:06d}".format(
+                "test" if render_test else "path", self.global_step))
+            os.makedirs(testsavedir, exist_ok=True)
+            _, _, avg_test_psnr = nerf_utils.render_path(
+                render_poses, hwf, self.K, self.chunk, render_kwargs_test, step=self.global_step,
+                save_scene_data=save_scene_data, gt_imgs=images, savedir=testsavedir, render_factor=self.render_factor)
+        return avg_test_psnr
+
     def train(self, N_iters=200000 + 1):
+        """render_only path of Trainer.train (Trainer.py:712-750): load data, build / reload the networks,
+        render the test (or spiral) poses, return the average PSNR.  The optimisation loop is out of scope."""
+        hwf, poses, i_test, i_val, i_train, images, render_poses = self.load_data()
+        dev = "cuda" if self.device == "cuda" else self.device
+        if self.render_test:
+            render_poses = torch.tensor(np.array(poses[i_test])).to(dev)
+        hwf = self.cast_intrinsics_to_right_types(hwf=hwf)
+        os.makedirs(os.path.join(self.basedir, self.expname), exist_ok=True)
+        optimizer, sampling_optimizer, render_kwargs_train, render_kwargs_test = self.create_nerf_model()
+        if self.train_depth_net_only:
+            for k in ("network_fn", "network_fine"):
+                if render_kwargs_train[k] is not None:
+                    utils.freeze_model(render_kwargs_train[k])
+        if self.render_only:
+            return self.render(self.render_test, self.save_scene_data, images, i_test, render_poses, hwf,
+                               render_kwargs_test)
         raise NotImplementedError(
-            "nerf_sampling_amd accelerates the render hot path only; dataset loading, render_path and the "
-            "optimisation loop of the reference are out of scope this round (SURVEY.md section 8f).")
+            "nerf_sampling_amd accelerates the render hot path; the optimisation loop (backward through DepthNet) "
+            "is the next scope row (SURVEY.md section 8f-2) and is not implemented.")
 
 
 class BlenderTrainer(Trainer):
@@ -132,6 +164,18 @@ class BlenderTrainer(Trainer):
         self.half_res, self.testskip, self.white_bkgd = half_res, testskip, white_bkgd
         self.near, self.far = near, far
         super().__init__(**kwargs)
+
+    def load_data(self):
+        """trainers/Blender.py:19-32."""
+        from .load_blender import load_blender_data
+
+        images, poses, render_poses, hwf, i_split = load_blender_data(self.datadir, self.half_res, self.testskip)
+        i_train, i_val, i_test = i_split
+        if self.white_bkgd:
+            images = images[..., :3] * images[..., -1:] + (1.0 - images[..., -1:])
+        else:
+            images = images[..., :3]
+        return hwf, poses, i_test, i_val, i_train, images, render_poses.clone().detach()
 
 
 class DepthNetTrainer(BlenderTrainer):
