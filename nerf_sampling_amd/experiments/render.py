@@ -1,0 +1,108 @@
+"""Counterpart of nerf_sampling/experiments/render.py: same flags, same yaml -> trainer -> train() flow,
+rendering through the HIP path.  wandb is out of scope (the -w flag is accepted and ignored).
+
+    python -m nerf_sampling_amd.experiments.render -d lego [-nf | -nm | -nc] [-e] [--dtype bf16]
+"""
+
+import os
+
+import click
+import torch
+import yaml
+
+from nerf_sampling_amd import ops
+from nerf_sampling_amd.utils import load_obj_from_config, override_config, set_global_device
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@click.command()
+@click.option("-c", "--config", help="Path to configuration file.", type=str,
+              default=f"{ROOT_DIR}/experiments/configs/lego.yaml", show_default=True)
+@click.option("-dp", "--dataset_path", help="Path to dataset folder.", type=str, show_default=True)
+@click.option("-d", "--dataset", help="Name of the dataset to render.", type=str, show_default=True)
+@click.option("-m", "--model", help="Model type.", type=str, default="lego_depth_net_module", show_default=True)
+@click.option("-w", "--wandb", default="disabled", help="Ignored (wandb logging is out of scope).", show_default=True)
+@click.option("-si", "--single_image", is_flag=True, default=False, show_default=True)
+@click.option("-sr", "--single_ray", is_flag=True, default=False, show_default=True)
+@click.option("-rt", "--render_test", is_flag=True, default=False, help="Perform render test", show_default=True)
+@click.option("-ssd", "--save_scene_data", is_flag=True, default=False, show_default=True)
+@click.option("-nc", "--nerf_compare", is_flag=True, default=False,
+              help="Compare depth network predictions to the original NeRF most important samples.", show_default=True)
+@click.option("-nm", "--nerf_max", is_flag=True, default=False, help="Use nerf max points to render", show_default=True)
+@click.option("-nf", "--nerf_full", is_flag=True, default=False, help="Use full nerf to render", show_default=True)
+@click.option("-e", "--experiments", is_flag=True, default=False, help="Use automatic experiments.", show_default=True)
+@click.option("-tmp", "--temporary", is_flag=True, default=False, help="Use temporary folder for experiment.",
+              show_default=True)
+@click.option("-ip", "--i_print", default=1000, help="Frequency of log printing.", show_default=True)
+@click.option("--dtype", default="bf16", type=click.Choice(["bf16", "f16", "f32"]), show_default=True,
+              help="MFMA operand precision of the HIP kernels (not in the reference).")
+@click.option("--root", default=os.getcwd(), show_default=True,
+              help="Directory holding dataset/ pretrained/ logs/ (the reference uses its package directory).")
+def main(**kw):
+    """Render with a pretrained NeRF + DepthNet (reference flow: render.py:135-272)."""
+    with open(kw["config"], "r") as fin:
+        config = yaml.safe_load(fin)[kw["model"]]
+    k = config["kwargs"]
+    k.update(single_image=kw["single_image"], single_ray=kw["single_ray"], save_scene_data=kw["save_scene_data"],
+             i_print=kw["i_print"], compare_nerf=kw["nerf_compare"], use_nerf_max_pts=kw["nerf_max"],
+             use_full_nerf=kw["nerf_full"], render_only=True, render_test=True)
+    root = kw["root"]
+    datadir, ft_path, depth_net_path = kw["dataset_path"], None, None
+    dataset_name = kw["dataset"]
+    if dataset_name is not None:
+        datadir = f"{root}/dataset/{dataset_name}"
+        ft_path = f"{root}/pretrained/nerf/{dataset_name}/200000.tar"
+        depth_net_path = f"{root}/pretrained/depth_net/{dataset_name}/files/sampler_experiment/200000.tar"
+    if datadir is None:
+        print("Please specify the name of the dataset or provide the path to the folder")
+        return
+    basedir = f"{root}/logs/{dataset_name}"
+    set_global_device(k["device"])
+    ops.set_compute_dtype(kw["dtype"])
+    override_config(config=k, update={"depth_net_lr": 1e-4, "n_layers": 10, "layer_width": 256,
+                                      "train_depth_net_only": True, "sphere_radius": 2})
+    torch.manual_seed(42)
+    k.update(datadir=datadir, basedir=basedir, ft_path=ft_path, depth_net_path=depth_net_path)
+    n_samples, distance, sampling_mode = 2, 0.01, "uniform"   # the reference's in-source defaults (render.py:208-212)
+
+    def expname(ns, dist, mode):
+        if kw["temporary"]:
+            return "tmp"
+        if kw["nerf_compare"]:
+            return f"{dataset_name}_depth_net_render_mse"
+        if kw["nerf_max"]:
+            return f"{dataset_name}_nerf_max_render"
+        if kw["nerf_full"]:
+            return f"{dataset_name}_nerf_full_render"
+        return f"{dataset_name}_depth_net_render_n_samples_{ns}_distance_{dist}_sampling_mode_{mode}"
+
+    if kw["experiments"]:  # the -e sweep of render.py:232-261
+        basedir = f"{root}/logs/{dataset_name}/experiments"
+        os.makedirs(basedir, exist_ok=True)
+        f = os.path.join(basedir, "experiments_results.txt")
+        with open(f, "w") as file:
+            file.write("Experiments")
+        for sampling_mode in ["uniform", "gaussian"]:
+            k["basedir"] = os.path.join(basedir, sampling_mode)
+            with open(f, "a") as file:
+                file.write(f"\n\nSampling mode: {sampling_mode}\n\n")
+            for n_samples in [2, 32, 64, 128]:
+                with open(f, "a") as file:
+                    file.write(f"N_samples: {n_samples}:\n")
+                for distance in [0.1, 0.3, 0.5, 1]:
+                    k.update(expname=f"{dataset_name}_depth_net_render_n_samples_{n_samples}_distance_{distance}"
+                                     f"_sampling_mode_{sampling_mode}",
+                             n_depth_samples=n_samples, distance=distance, sampling_mode=sampling_mode)
+                    psnr = load_obj_from_config(cfg=config).train()
+                    with open(f, "a") as file:
+                        file.write(f"    Distance: {distance}, PSNR: {psnr:.2f}\n")
+        return
+    k.update(expname=expname(n_samples, distance, sampling_mode), n_depth_samples=n_samples, distance=distance,
+             sampling_mode=sampling_mode)
+    psnr = load_obj_from_config(cfg=config).train()
+    print(f"Final psnr: {psnr}")
+
+
+if __name__ == "__main__":
+    main()

@@ -91,3 +91,44 @@ def test_render_only_pipeline_with_reference_checkpoints(tmp_path, gpu_modules):
     assert psnr > 50.0          # vs its own 8-bit ground truth: quantisation noise only (~59 dB)
     sd = torch.load(os.path.join(out_dir, "scene_data.pt"), weights_only=True)
     assert sd["all_pts"].shape == (2 * H * W * 16, 3) and sd["all_weights"].shape == (2 * H * W * 16,)
+
+
+@pytest.mark.gpu
+def test_render_cli_counterpart(tmp_path, gpu_modules):
+    """`python -m nerf_sampling_amd.experiments.render -d lego -rt [-nf]`: the reference's CLI flow
+    (render.py:135-272) on a synthetic 'lego' with production-size networks and reference-layout paths."""
+    from click.testing import CliRunner
+
+    from nerf_sampling_amd.experiments.render import main
+    from nerf_sampling_amd.synthetic import pose_spherical
+
+    m = gpu_modules("lego_synth")
+    root = str(tmp_path)
+    H = W = 16   # files are 32x32, the yaml has half_res: True
+    rng = np.random.default_rng(1)
+    frames = [np.concatenate([rng.integers(0, 256, (2 * H, 2 * W, 3), dtype=np.uint8), np.full((2 * H, 2 * W, 1), 255, np.uint8)], -1)
+              for _ in range(2)]
+    poses = [pose_spherical(a, -30.0, 4.0).numpy() for a in (0.0, 90.0)]
+    _write_dataset(os.path.join(root, "dataset", "lego"), {"train": frames[:1], "val": frames[:1], "test": frames},
+                   {"train": poses[:1], "val": poses[:1], "test": poses})
+    os.makedirs(os.path.join(root, "pretrained", "nerf", "lego"))
+    os.makedirs(os.path.join(root, "pretrained", "depth_net", "lego", "files", "sampler_experiment"))
+    both = list(m["coarse"].parameters()) + list(m["fine"].parameters())
+    torch.save({"global_step": 200000, "network_fn_state_dict": m["coarse"].state_dict(),
+                "network_fine_state_dict": m["fine"].state_dict(),
+                "optimizer_state_dict": torch.optim.Adam(both).state_dict()},
+               os.path.join(root, "pretrained", "nerf", "lego", "200000.tar"))
+    torch.save({"global_step": 200000, "depth_network": m["depth"].state_dict(),
+                "sampling_optimizer_state_dict": torch.optim.Adam(m["depth"].parameters()).state_dict()},
+               os.path.join(root, "pretrained", "depth_net", "lego", "files", "sampler_experiment", "200000.tar"))
+    try:
+        for flags, exp in (([], "lego_depth_net_render_n_samples_2_distance_0.01_sampling_mode_uniform"),
+                           (["-nf"], "lego_nerf_full_render")):
+            res = CliRunner().invoke(main, ["-d", "lego", "-rt", "--root", root, "--dtype", "f32"] + flags,
+                                     catch_exceptions=False)
+            assert res.exit_code == 0, res.output
+            assert "Final psnr" in res.output
+            out_dir = os.path.join(root, "logs", "lego", exp, "renderonly_test_200000")
+            assert os.path.exists(os.path.join(out_dir, "000.png")) and os.path.exists(os.path.join(out_dir, "psnr.txt"))
+    finally:
+        torch.set_default_device("cpu")   # the CLI switches the global default device like the reference does
