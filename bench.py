@@ -185,13 +185,25 @@ def main():
             and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
 
+    # "PSNR vs reference" leg of the metric, outside the timed region: this dtype against the fp32 parity path of the
+    # same build (which matches the reference to 5e-6, tests/test_gpu_render.py) on a 64-row band of the last frame
+    psnr_db = None
+    if rank == 0 and args.mode == "depthnet":
+        band = (H // 2 - 32, H // 2 + 32)
+        c2w_last = poses[(args.warmup + args.steps - 1) % 40]
+        kw = dict(camera=(H, W, K, c2w_last, band[0], band[1]), n_samples=args.samples, mode="uniform", std=0.1, device=device)
+        a = ops.render_rays_depthnet(depth_w, nerf_w, **kw)["rgb"]
+        b = ops.render_rays_depthnet(dn.packed("f32"), fine.packed("f32"), **kw)["rgb"]
+        mse = float(((a - b) ** 2).mean())
+        psnr_db = float("inf") if mse == 0 else -10.0 * float(np.log10(mse))
+
     if rank == 0:
         rays = H * W * args.steps
         out = {
             "metric": "rays/sec at 800x800, 64 samples/ray; PSNR vs reference",
             "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "psnr_vs_fp32_path_db": psnr_db,
             "config": {"workload": (f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "
                                     f"(std 0.1) through the NeRF 8x256 fine MLP" if args.mode == "depthnet" else
                                     f"Lego-shaped {H}x{W} frame, vanilla hierarchical 64 coarse + 128 importance "
