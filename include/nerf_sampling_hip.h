@@ -211,6 +211,30 @@ typedef struct ns_hier_args {
 int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf);
 int ns_render_rays_hierarchical(const ns_hier_args* args, void* stream);
 
+/* ---- training step of the DepthNet (Trainer.core_optimization_loop, Trainer.py:506-544) -------------
+ * Batches are N_rand = 1024 rays, so these are small fp32 kernels (exact-fp32 MFMA products), not the
+ * fused inference path.  One strided GEMM serves nn.Linear forward (y = x W^T + b), grad-input
+ * (dx = dy W) and grad-weight (dW = dy^T x):
+ *   C[i,j] (+)= sum_k A[i*sa0 + k*sa1] * B[j*sb0 + k*sb1] (+ bias[j]),  C row-major with leading dim ldc */
+int ns_gemm_strided(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0,
+                    int64_t sb1, const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K,
+                    int accumulate, void* stream);
+/* out[j] = sum_i X[i*ld + j]  (bias gradient) */
+int ns_colsum(const float* X_dev, int64_t ld, int M, int N, float* out_dev, void* stream);
+/* activations in place: act 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 sigmoid; backward scales dy by act'(.)
+ * evaluated from the activation OUTPUT y                                                            */
+int ns_act_forward(float* y_dev, int64_t n, int act, void* stream);
+int ns_act_backward(float* dy_dev, const float* y_dev, int64_t n, int act, void* stream);
+/* gradient of Embedder.embed w.r.t. its input: x [M,d], de [M,d(1+2L)] -> dx [M,d] */
+int ns_posenc_backward(const float* x_dev, const float* de_dev, int64_t M, int d, int n_freqs,
+                       float* dx_dev, void* stream);
+/* gradient of pts = o + d*z w.r.t. z: dpts [R,N,3], d [R,3] -> dz [R,N] */
+int ns_points_backward(const float* dpts_dev, const float* d_dev, int64_t R, int N, float* dz_dev,
+                       void* stream);
+/* torch.optim.Adam update (no weight decay / amsgrad), step counted from 1 */
+int ns_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
+                 float beta1, float beta2, float eps, int step, void* stream);
+
 /* ---- timing helpers (hipEvent_t as void*) used by bench.py for the live roofline figure --------- */
 int ns_event_create(void** ev);
 void ns_event_destroy(void* ev);

@@ -84,6 +84,13 @@ SIGNATURES = {
     "ns_render_rays_depthnet": (_i, [C.POINTER(RenderArgs), _p]),
     "ns_hier_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ns_render_rays_hierarchical": (_i, [C.POINTER(HierArgs), _p]),
+    "ns_gemm_strided": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "ns_colsum": (_i, [_p, _i64, _i, _i, _p, _p]),
+    "ns_act_forward": (_i, [_p, _i64, _i, _p]),
+    "ns_act_backward": (_i, [_p, _p, _i64, _i, _p]),
+    "ns_posenc_backward": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "ns_points_backward": (_i, [_p, _p, _i64, _i, _p, _p]),
+    "ns_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
     "ns_event_create": (_i, [C.POINTER(_p)]),
     "ns_event_destroy": (None, [_p]),
     "ns_event_record": (_i, [_p, _p]),

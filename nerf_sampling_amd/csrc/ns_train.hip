@@ -1,0 +1,205 @@
+// Kernels for the DepthNet training step (Trainer.core_optimization_loop, Trainer.py:506-544): the
+// backward of the layers the optimiser actually updates (DepthNet: weights) or differentiates through
+// (frozen NeRF: input points only; N=1 compositing: sigmoid).  Batches are 1024 rays (lego.yaml N_rand),
+// i.e. a few GFLOP per step -- launch-bound, so one generic strided fp32 MFMA GEMM
+// (v_mfma_f32_32x32x2_f32, exact fp32 products) serves forward, grad-input and grad-weight alike.
+#include "ns_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+// C[i,j] (+)= sum_k A[i*sa0 + k*sa1] * B[j*sb0 + k*sb1]  (+ bias[j]),  i < M, j < N, k < K
+// 256 threads = 4 waves, each a 32x32 sub-tile of the 64x64 workgroup tile.
+__global__ void __launch_bounds__(256)
+gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const float* __restrict__ B,
+                    int64_t sb0, int64_t sb1, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                    int M, int N, int K, int accumulate) {
+  __shared__ float As[TM][TK + 1];
+  __shared__ float Bs[TN][TK + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += TK) {
+    for (int e = threadIdx.x; e < TM * TK; e += 256) {
+      const int r = e / TK, kk = e % TK;
+      const int i = i0 + r, j = j0 + r, k = k0 + kk;
+      As[r][kk] = (i < M && k < K) ? A[i * sa0 + k * sa1] : 0.f;
+      Bs[r][kk] = (j < N && k < K) ? B[j * sb0 + k * sb1] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TK; kk += 2) {
+      const float a = As[wr + (lane & 31)][kk + (lane >> 5)];
+      const float b = Bs[wc + (lane & 31)][kk + (lane >> 5)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int j = j0 + wc + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (i < M && j < N) {
+      float v = acc[r] + (bias ? bias[j] : 0.f);
+      float* c = C + i * ldc + j;
+      *c = accumulate ? *c + v : v;
+    }
+  }
+}
+
+// column sums: out[j] = sum_i X[i*ld + j]   (bias gradient)
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ X, int64_t ld, int M, int N, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float s = 0.f;
+  for (int i = 0; i < M; ++i) s += X[i * ld + j];
+  out[j] = s;
+}
+
+// activation forward in place / backward: act 0 none, 1 relu, 2 leaky(0.01), 3 sigmoid
+__global__ void __launch_bounds__(256)
+act_forward_kernel(float* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = y[i];
+    y[i] = act == 1 ? fmaxf(v, 0.f) : act == 2 ? (v > 0.f ? v : 0.01f * v) : act == 3 ? 1.f / (1.f + expf(-v)) : v;
+  }
+}
+// dy *= act'(.) given the activation OUTPUT y
+__global__ void __launch_bounds__(256)
+act_backward_kernel(float* __restrict__ dy, const float* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = y[i];
+    const float g = act == 1 ? (v > 0.f ? 1.f : 0.f) : act == 2 ? (v > 0.f ? 1.f : 0.01f) : act == 3 ? v * (1.f - v) : 1.f;
+    dy[i] *= g;
+  }
+}
+
+// d/dx of the positional encoding: x [M,d], de [M, d(1+2L)] -> dx [M,d]
+__global__ void __launch_bounds__(256)
+posenc_backward_kernel(const float* __restrict__ x, const float* __restrict__ de, int64_t M, int d, int L,
+                       float* __restrict__ dx) {
+  const int width = d * (1 + 2 * L);
+  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < M * d; e += (int64_t)gridDim.x * 256) {
+    const int64_t m = e / d;
+    const int c = static_cast<int>(e % d);
+    const float v = x[e];
+    const float* g = de + m * width;
+    float s = g[c];
+    for (int l = 0; l < L; ++l) {
+      const float f = exp2f(static_cast<float>(l));
+      float sn, cs;
+      sincosf(v * f, &sn, &cs);
+      s += f * (cs * g[d + 2 * d * l + c] - sn * g[d + 2 * d * l + d + c]);
+    }
+    dx[e] = s;
+  }
+}
+
+// dz[r] (+)= sum_c dpts[r,n,c] * d[r,c]   for pts = o + d*z with N samples per ray
+__global__ void __launch_bounds__(256)
+points_backward_kernel(const float* __restrict__ dpts, const float* __restrict__ d, int64_t R, int N,
+                       float* __restrict__ dz) {
+  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < R * N; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / N;
+    dz[e] = (dpts[e * 3] * d[r * 3] + dpts[e * 3 + 1] * d[r * 3 + 1]) + dpts[e * 3 + 2] * d[r * 3 + 2];
+  }
+}
+
+// torch.optim.Adam step (no weight decay, no amsgrad), in place
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = m[i] = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = v[i] = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ns_gemm_strided(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0, int64_t sb1,
+                    const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K, int accumulate,
+                    void* stream) {
+  NS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "bad shape");
+  if (M == 0 || N == 0) return NS_OK;
+  NS_REQUIRE(A_dev && B_dev && C_dev, "null pointer");
+  dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM);
+  gemm_strided_kernel<<<grid, 256, 0, ns::as_stream(stream)>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, C_dev, ldc,
+                                                              M, N, K, accumulate);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_colsum(const float* X_dev, int64_t ld, int M, int N, float* out_dev, void* stream) {
+  NS_REQUIRE(M >= 0 && N >= 0, "bad shape");
+  if (N == 0) return NS_OK;
+  NS_REQUIRE(X_dev && out_dev, "null pointer");
+  colsum_kernel<<<(N + 255) / 256, 256, 0, ns::as_stream(stream)>>>(X_dev, ld, M, N, out_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_act_forward(float* y_dev, int64_t n, int act, void* stream) {
+  NS_REQUIRE(n >= 0 && act >= 0 && act <= 3, "bad argument");
+  if (n == 0 || act == 0) return NS_OK;
+  NS_REQUIRE(y_dev, "null pointer");
+  act_forward_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(y_dev, n, act);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_act_backward(float* dy_dev, const float* y_dev, int64_t n, int act, void* stream) {
+  NS_REQUIRE(n >= 0 && act >= 0 && act <= 3, "bad argument");
+  if (n == 0 || act == 0) return NS_OK;
+  NS_REQUIRE(dy_dev && y_dev, "null pointer");
+  act_backward_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(dy_dev, y_dev, n, act);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_posenc_backward(const float* x_dev, const float* de_dev, int64_t M, int d, int n_freqs, float* dx_dev,
+                       void* stream) {
+  NS_REQUIRE(M >= 0 && d > 0 && n_freqs >= 0, "bad shape");
+  if (M == 0) return NS_OK;
+  NS_REQUIRE(x_dev && de_dev && dx_dev, "null pointer");
+  posenc_backward_kernel<<<ns::ew_grid(M * d, 256), 256, 0, ns::as_stream(stream)>>>(x_dev, de_dev, M, d, n_freqs,
+                                                                                    dx_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_points_backward(const float* dpts_dev, const float* d_dev, int64_t R, int N, float* dz_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 1, "bad shape");
+  if (R == 0) return NS_OK;
+  NS_REQUIRE(dpts_dev && d_dev && dz_dev, "null pointer");
+  points_backward_kernel<<<ns::ew_grid(R * N, 256), 256, 0, ns::as_stream(stream)>>>(dpts_dev, d_dev, R, N, dz_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int step, void* stream) {
+  NS_REQUIRE(n >= 0 && step >= 1, "bad argument");
+  if (n == 0) return NS_OK;
+  NS_REQUIRE(p_dev && g_dev && m_dev && v_dev, "null pointer");
+  const float bc1 = 1.f - powf(beta1, static_cast<float>(step));
+  const float bc2 = 1.f - powf(beta2, static_cast<float>(step));
+  adam_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2,
+                                                                     eps, bc1, bc2);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+}  // extern "C"

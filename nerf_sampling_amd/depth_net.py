@@ -79,6 +79,14 @@ class DepthNet(nn.Module):
         return r
 
     def forward(self, rays_o: torch.Tensor, rays_d: torch.Tensor):
-        """[R,3], [R,3] -> depth [R,1] in [near, far] (depth_net.py:117-169)."""
+        """[R,3], [R,3] -> depth [R,1] in [near, far] (depth_net.py:117-169).
+
+        Under autograd with trainable weights the layer-by-layer differentiable path is used
+        (nerf_sampling_amd.autograd.DepthNetFunction); otherwise the fused inference kernel."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import depthnet_forward_train
+
+            self._packed = {}  # weights are about to change
+            return depthnet_forward_train(self, rays_o, rays_d)
         return ops.depthnet_forward(self.packed(), rays_o, rays_d, self.near, self.far,
                                     float(self.sphere_radius.reshape(-1)[0]))

@@ -222,23 +222,28 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, trainer, ret
     """Training operator, forward (nerf_utils.py:614-733); same keys / host copies as the reference."""
     rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
     viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
-    (_dens, fine_z, _pts, _rgb, fine_w, _al, _disp, _raw) = sample_as_in_NeRF(
-        ray_batch=ray_batch, N_samples=N_samples, network_fn=network_fn, network_fine=network_fine,
-        network_query_fn=network_query_fn, trainer=trainer, perturb=perturb, raw_noise_std=raw_noise_std,
-        lindisp=lindisp, white_bkgd=white_bkgd, pytest=pytest, kwargs=kwargs)
-    max_z_vals, _, _ = ops.argmax_gather(fine_w, fine_z)
-    max_pts = ops.points_along_rays(rays_o, rays_d, max_z_vals)
+    # the vanilla pass only provides the regression target max_z: frozen networks, detached samples
+    # (Trainer.py:569) -- no gradient reaches the DepthNet through it
+    with torch.no_grad():
+        (_dens, fine_z, _pts, _rgb, fine_w, _al, _disp, _raw) = sample_as_in_NeRF(
+            ray_batch=ray_batch, N_samples=N_samples, network_fn=network_fn, network_fine=network_fine,
+            network_query_fn=network_query_fn, trainer=trainer, perturb=perturb, raw_noise_std=raw_noise_std,
+            lindisp=lindisp, white_bkgd=white_bkgd, pytest=pytest, kwargs=kwargs)
+        max_z_vals, _, _ = ops.argmax_gather(fine_w, fine_z)
+        max_pts = ops.points_along_rays(rays_o, rays_d, max_z_vals)
+    from .autograd import points_along_rays as points_along_rays_ag
+
     depth_net_z_vals = kwargs["depth_network"](rays_o, rays_d)
-    depth_net_pts = ops.points_along_rays(rays_o, rays_d, depth_net_z_vals)
+    depth_net_pts = points_along_rays_ag(rays_o, rays_d, depth_net_z_vals)
     net = network_fine if network_fine is not None else network_fn
     depth_net_raw = network_query_fn(depth_net_pts, viewdirs, net)
     (rgb_map, disp_map, _acc, _depth, _density, _alphas, _weights) = trainer.raw2outputs(
         raw=depth_net_raw, z_vals=depth_net_z_vals, rays_d=rays_d, raw_noise=raw_noise_std, white_bkdg=white_bkgd,
         pytest=pytest)  # (sic) misspelled keywords, as in the reference: noise 0, white background
     ret = {"depth_net_rgb_map": rgb_map, "depth_net_disp_map": disp_map, "depth_net_z_vals": depth_net_z_vals,
-           "max_z_vals": max_z_vals, "depth_net_pts": depth_net_pts.cpu(), "max_pts": max_pts.cpu()}
+           "max_z_vals": max_z_vals, "depth_net_pts": depth_net_pts.detach().cpu(), "max_pts": max_pts.cpu()}
     if retraw:
-        ret["raw"] = depth_net_raw.cpu()
+        ret["raw"] = depth_net_raw.detach().cpu()
     return ret
 
 

@@ -59,6 +59,10 @@ class Trainer:
                  and viewdirs is not None and embed_fn.num_freqs == 10 and embeddirs_fn.num_freqs == 4
                  and embed_fn.input_dims == 3 and embeddirs_fn.input_dims == 3)
         if fused:
+            if torch.is_grad_enabled() and inputs.requires_grad:   # training: gradient w.r.t. the points only
+                from .autograd import NerfInputGrad
+
+                return NerfInputGrad.apply(inputs, viewdirs, fn)
             return ops.nerf_forward(fn.packed(), inputs, viewdirs)
         inputs_flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
         embedded = embed_fn(inputs_flat)
@@ -154,9 +158,72 @@ class Trainer:
         if self.render_only:
             return self.render(self.render_test, self.save_scene_data, images, i_test, render_poses, hwf,
                                render_kwargs_test)
-        raise NotImplementedError(
-            "nerf_sampling_amd accelerates the render hot path; the optimisation loop (backward through DepthNet) "
-            "is the next scope row (SURVEY.md section 8f-2) and is not implemented.")
+        if self.use_batching:
+            raise NotImplementedError("use_batching (rays shuffled over all images) is not implemented; the "
+                                      "experiments run with no_batching: True (lego.yaml)")
+        poses = torch.tensor(np.asarray(poses)).to(dev)
+        psnr = None
+        for i in range(self.start + 1, N_iters):
+            _, _, batch_rays, target_s = self.sample_random_ray_batch(None, 0, i_train, images, poses, i)
+            loss, depth_net_loss, psnr, _ = self.core_optimization_loop(sampling_optimizer, render_kwargs_train,
+                                                                         batch_rays, i, target_s)
+            self.update_learning_rate(optimizer)
+            if i % self.i_print == 0:
+                print(f"[TRAIN] Iter: {i} Loss: {float(loss)} depth_net_loss: {float(depth_net_loss)} "
+                      f"PSNR: {float(psnr)}")
+            if i % self.i_weights == 0:
+                path = os.path.join(self.basedir, self.expname, "{:06d}.tar".format(i))
+                utils.save_state(self.global_step, render_kwargs_train["network_fn"],
+                                 render_kwargs_train["network_fine"], optimizer, render_kwargs_train["depth_network"],
+                                 sampling_optimizer, path)
+            self.global_step += 1
+        return psnr
+
+    def update_learning_rate(self, optimizer):
+        """Trainer.py:546-551 (decays the NeRF optimiser's lr, which never steps when train_depth_net_only)."""
+        new_lrate = self.lrate * (0.1 ** (self.global_step / (self.lrate_decay * 1000)))
+        for param_group in optimizer.param_groups:
+            param_group["lr"] = new_lrate
+
+    def sample_random_ray_batch(self, rays_rgb, i_batch, i_train, images, poses, i):
+        """N_rand random pixels of one random training image (the no_batching branch of Trainer.py:400-475)."""
+        img_i = 42 if self.single_image else np.random.choice(i_train)
+        target = torch.tensor(np.asarray(images[img_i]), dtype=torch.float32)
+        pose = poses[img_i, :3, :4]
+        self.c2w = pose.clone().detach()
+        rays_o, rays_d, _ = ops.get_rays(self.H, self.W, self.K, self.c2w)     # [H*W, 3]
+        if i < self.precrop_iters:
+            dH, dW = int(self.H // 2 * self.precrop_frac), int(self.W // 2 * self.precrop_frac)
+            rows = torch.arange(self.H // 2 - dH, self.H // 2 + dH)
+            cols = torch.arange(self.W // 2 - dW, self.W // 2 + dW)
+        else:
+            rows, cols = torch.arange(self.H), torch.arange(self.W)
+        coords = torch.stack(torch.meshgrid(rows, cols, indexing="ij"), -1).reshape(-1, 2)
+        if self.single_ray:
+            select = np.array([91])
+        else:
+            select = np.random.choice(coords.shape[0], size=[self.N_rand], replace=False)
+        sel = coords[select].long()
+        flat = (sel[:, 0] * self.W + sel[:, 1]).to(rays_o.device)
+        batch_rays = torch.stack([rays_o[flat], rays_d[flat]], 0)
+        target_s = target[sel[:, 0], sel[:, 1]].to(rays_o.device)
+        return rays_rgb, i_batch, batch_rays, target_s
+
+    def core_optimization_loop(self, sampling_optimizer, render_kwargs_train, batch_rays, i, target_s):
+        """One DepthNet update: (loss, depth_net_loss, psnr, psnr0) -- Trainer.py:506-544.  The two backward
+        calls of the reference accumulate into the same .grad; one backward of the sum is identical."""
+        from .run_nerf_helpers import img2mse, mse2psnr
+
+        rgb, _disp, extras = nerf_utils.render(self.H, self.W, self.K, chunk=self.chunk, rays=batch_rays,
+                                               verbose=i < 10, retraw=True, **render_kwargs_train)
+        sampling_optimizer.zero_grad()
+        img_loss = img2mse(rgb, target_s)
+        psnr = mse2psnr(img_loss.detach())
+        depth_net_loss = torch.nn.functional.mse_loss(extras["depth_net_z_vals"], extras["max_z_vals"])
+        (depth_net_loss + img_loss).backward()
+        sampling_optimizer.step()
+        render_kwargs_train["depth_network"].repack()
+        return img_loss.detach(), depth_net_loss.detach(), psnr, None
 
 
 class BlenderTrainer(Trainer):
@@ -201,7 +268,9 @@ class DepthNetTrainer(BlenderTrainer):
         sizes = [self.layer_width for _ in range(self.n_layers)]
         dev = "cuda" if self.device == "cuda" else self.device
         depth_network = DepthNet(hidden_sizes=sizes, cat_hidden_sizes=list(sizes), sphere_radius=self.sphere_radius).to(dev)
-        sampling_optimizer = torch.optim.Adam(params=list(depth_network.parameters()), lr=self.depth_net_lr)
+        from .autograd import HipAdam
+
+        sampling_optimizer = HipAdam(params=list(depth_network.parameters()), lr=self.depth_net_lr)
         ckpts = []
         if self.depth_net_path is not None and self.depth_net_path != "None":
             ckpts = [self.depth_net_path]
@@ -239,5 +308,14 @@ class DepthNetTrainer(BlenderTrainer):
             zeros = torch.zeros((R,), device=raw.device)
             return (torch.zeros((R, 3), device=raw.device), torch.full((R,), 1e10, device=raw.device), zeros,
                     zeros.clone(), density, raw[..., 3].clone(), raw[..., 3].clone())
+        if torch.is_grad_enabled() and raw.requires_grad:
+            if z_vals.shape[-1] != 1 or noise is not None:
+                raise NotImplementedError("autograd through compositing is implemented for the single-sample "
+                                          "training path only (nerf_utils.py:692-715)")
+            from .autograd import SingleSampleComposite
+
+            rgb_map, disp_map, acc_map, depth_map, alphas, weights = SingleSampleComposite.apply(
+                raw, z_vals, rays_d, bool(white_bkgd))
+            return rgb_map, disp_map, acc_map, depth_map, density, alphas, weights
         rgb_map, disp_map, acc_map, depth_map, alphas, weights = ops.raw2outputs(raw, z_vals, rays_d, noise, white_bkgd)
         return rgb_map, disp_map, acc_map, depth_map, density, alphas, weights

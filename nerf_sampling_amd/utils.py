@@ -45,6 +45,20 @@ def unfreeze_model(model):
         p.requires_grad = True
 
 
+def save_state(global_step, network_fn, network_fine, optimizer, depth_network, sampling_optimizer, path) -> None:
+    """Checkpoint in the reference's layout (utils.py:59-89)."""
+    data = {
+        "global_step": global_step,
+        "network_fn_state_dict": network_fn.state_dict(),
+        "optimizer_state_dict": optimizer.state_dict(),
+        "sampling_optimizer_state_dict": sampling_optimizer.state_dict(),
+        "depth_network": depth_network.state_dict(),
+    }
+    if network_fine is not None:
+        data["network_fine_state_dict"] = network_fine.state_dict()
+    torch.save(data, path)
+
+
 def load_nerf(network_fn, network_fine, optimizer, ckpt):
     """Checkpoint keys as written by the reference's save_state (utils.py:59-106)."""
     if optimizer is not None:

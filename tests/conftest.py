@@ -63,6 +63,9 @@ def _make_modules(scene_name):
     dn.load_state_dict(params["depth"])
     out["depth"] = dn.to("cuda")
     out["params"] = params
+    for k in ("coarse", "fine", "depth"):      # inference fixtures: frozen (the training test unfreezes DepthNet)
+        for p in out[k].parameters():
+            p.requires_grad_(False)
     return out
 
 
