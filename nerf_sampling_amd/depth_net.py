@@ -73,6 +73,12 @@ class DepthNet(nn.Module):
     def repack(self):
         self._packed = {}
 
+    def __getstate__(self):
+        # packed device weight streams are caches of the parameters: never pickled / deep-copied
+        state = self.__dict__.copy()
+        state["_packed"] = {}
+        return state
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.repack()

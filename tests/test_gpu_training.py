@@ -2,6 +2,7 @@
 of the oracle: gradients of every DepthNet parameter, the Adam update, and a short optimisation run."""
 
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -134,3 +135,79 @@ def test_core_optimization_loop_reduces_loss(gpu_modules):
     print("depth_net_loss:", [round(x, 5) for x in losses])
     assert losses[-1] < losses[0]
     assert all(torch.equal(a, b) for a, b in zip(fine_before, m["fine"].parameters()))
+
+
+def test_train_loop_end_to_end(tmp_path, gpu_modules):
+    """DepthNetTrainer.train(): Blender dataset -> random ray batches -> DepthNet updates -> checkpoints in the
+    reference's layout (utils.py:59-89) that reload into a fresh trainer."""
+    from test_render_path import _write_dataset
+
+    from nerf_sampling_amd import ops
+    from nerf_sampling_amd.trainers import DepthNetTrainer
+
+    ops.set_compute_dtype("f32")
+    m = gpu_modules("tiny_synth")
+    rng = np.random.default_rng(3)
+    H = W = 20
+    frames = [np.concatenate([rng.integers(0, 256, (H, W, 3), dtype=np.uint8), np.full((H, W, 1), 255, np.uint8)], -1)
+              for _ in range(3)]
+    poses = [O.pose_spherical(a, -30.0, 4.0).numpy() for a in (0.0, 120.0, 240.0)]
+    data, logs = str(tmp_path / "data"), str(tmp_path / "logs")
+    _write_dataset(data, {"train": frames, "val": frames[:1], "test": frames[:1]},
+                   {"train": poses, "val": poses[:1], "test": poses[:1]})
+    nerf_ckpt = str(tmp_path / "nerf.tar")
+    both = list(m["coarse"].parameters()) + list(m["fine"].parameters())
+    torch.save({"global_step": 0, "network_fn_state_dict": m["coarse"].state_dict(),
+                "network_fine_state_dict": m["fine"].state_dict(),
+                "optimizer_state_dict": torch.optim.Adam(both).state_dict()}, nerf_ckpt)
+    kw = dict(dataset_type="blender", basedir=logs, expname="exp", no_batching=True, datadir=data, half_res=False,
+              white_bkgd=True, testskip=1, device="cuda", N_rand=128, N_importance=128, N_samples=64, use_viewdirs=True,
+              input_dims_embed=3, netdepth=4, netwidth=128, netdepth_fine=4, netwidth_fine=128, n_layers=3,
+              layer_width=128, sphere_radius=2.0, ft_path=nerf_ckpt, depth_net_lr=1e-3, train_depth_net_only=True,
+              i_weights=3, i_print=2, perturb=0.0)
+    np.random.seed(0); torch.manual_seed(0)
+    tr = DepthNetTrainer(**kw)
+    psnr = tr.train(N_iters=7)                   # iterations 1..6, checkpoints at 3 and 6
+    assert psnr is not None and np.isfinite(float(psnr))
+    ckpts = sorted(f for f in os.listdir(os.path.join(logs, "exp")) if f.endswith(".tar"))
+    assert ckpts == ["000003.tar", "000006.tar"]
+    ck = torch.load(os.path.join(logs, "exp", "000006.tar"), weights_only=True)
+    assert set(ck) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict",
+                       "sampling_optimizer_state_dict", "depth_network"}
+    assert "origin_layers.0.weight" in ck["depth_network"] and "cat_layers.4.bias" in ck["depth_network"]
+    # NeRF stayed frozen, DepthNet moved
+    assert torch.equal(ck["network_fine_state_dict"]["pts_linears.0.weight"].cpu(), m["fine"].pts_linears[0].weight.cpu())
+    # resume: a new trainer on the same expdir reloads the newest DepthNet checkpoint and its step
+    tr2 = DepthNetTrainer(**kw)
+    tr2.create_nerf_model()
+    assert tr2.start == ck["global_step"]
+
+
+def test_run_cli_counterpart(tmp_path, gpu_modules):
+    """`python -m nerf_sampling_amd.experiments.run -d lego --iters 2`: production-size DepthNet (10x256, lr 1e-4)
+    trained for two steps against the frozen synthetic NeRF, reference directory layout."""
+    from click.testing import CliRunner
+    from test_render_path import _write_dataset
+
+    from nerf_sampling_amd.experiments.run import main
+
+    m = gpu_modules("lego_synth")
+    root = str(tmp_path)
+    rng = np.random.default_rng(5)
+    frames = [np.concatenate([rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), np.full((64, 64, 1), 255, np.uint8)], -1)
+              for _ in range(2)]
+    poses = [O.pose_spherical(a, -30.0, 4.0).numpy() for a in (0.0, 90.0)]
+    _write_dataset(os.path.join(root, "dataset", "lego"), {"train": frames, "val": frames[:1], "test": frames[:1]},
+                   {"train": poses, "val": poses[:1], "test": poses[:1]})
+    os.makedirs(os.path.join(root, "pretrained", "nerf", "lego"))
+    both = list(m["coarse"].parameters()) + list(m["fine"].parameters())
+    torch.save({"global_step": 0, "network_fn_state_dict": m["coarse"].state_dict(),
+                "network_fine_state_dict": m["fine"].state_dict(),
+                "optimizer_state_dict": torch.optim.Adam(both).state_dict()},
+               os.path.join(root, "pretrained", "nerf", "lego", "200000.tar"))
+    try:
+        res = CliRunner().invoke(main, ["-d", "lego", "--root", root, "--iters", "2", "-ip", "1"], catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+        assert "[TRAIN] Iter: 2" in res.output
+    finally:
+        torch.set_default_device("cpu")
