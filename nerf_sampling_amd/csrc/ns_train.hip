@@ -9,7 +9,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int TM = 64, TN = 64, TK = 32;
 
 // C[i,j] (+)= sum_k A[i*sa0 + k*sa1] * B[j*sb0 + k*sb1]  (+ bias[j]),  i < M, j < N, k < K
 // 256 threads = 4 waves, each a 32x32 sub-tile of the 64x64 workgroup tile.
@@ -26,11 +26,19 @@ gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int k0 = 0; k0 < K; k0 += TK) {
+    // consecutive threads walk whichever index is contiguous in memory (k for x / W rows, the row index
+    // for the transposed operands of the grad-weight product), so global loads coalesce in every variant
     for (int e = threadIdx.x; e < TM * TK; e += 256) {
-      const int r = e / TK, kk = e % TK;
-      const int i = i0 + r, j = j0 + r, k = k0 + kk;
-      As[r][kk] = (i < M && k < K) ? A[i * sa0 + k * sa1] : 0.f;
-      Bs[r][kk] = (j < N && k < K) ? B[j * sb0 + k * sb1] : 0.f;
+      {
+        const int r = (sa1 == 1) ? e / TK : e % TM, kk = (sa1 == 1) ? e % TK : e / TM;
+        const int i = i0 + r, k = k0 + kk;
+        As[r][kk] = (i < M && k < K) ? A[i * sa0 + k * sa1] : 0.f;
+      }
+      {
+        const int r = (sb1 == 1) ? e / TK : e % TN, kk = (sb1 == 1) ? e % TK : e / TN;
+        const int j = j0 + r, k = k0 + kk;
+        Bs[r][kk] = (j < N && k < K) ? B[j * sb0 + k * sb1] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -53,14 +61,19 @@ gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const
   }
 }
 
-// column sums: out[j] = sum_i X[i*ld + j]   (bias gradient)
+// column sums: out[j] = sum_i X[i*ld + j]   (bias gradient).  Block = 64 columns x 4 row lanes; coalesced
+// 256-B row segments, LDS reduction over the row lanes.
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ X, int64_t ld, int M, int N, float* __restrict__ out) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= N) return;
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int i = 0; i < M; ++i) s += X[i * ld + j];
-  out[j] = s;
+  if (j < N)
+    for (int i = rl; i < M; i += 4) s += X[i * ld + j];
+  part[rl][c] = s;
+  __syncthreads();
+  if (rl == 0 && j < N) out[j] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // activation forward in place / backward: act 0 none, 1 relu, 2 leaky(0.01), 3 sigmoid
@@ -146,7 +159,7 @@ int ns_colsum(const float* X_dev, int64_t ld, int M, int N, float* out_dev, void
   NS_REQUIRE(M >= 0 && N >= 0, "bad shape");
   if (N == 0) return NS_OK;
   NS_REQUIRE(X_dev && out_dev, "null pointer");
-  colsum_kernel<<<(N + 255) / 256, 256, 0, ns::as_stream(stream)>>>(X_dev, ld, M, N, out_dev);
+  colsum_kernel<<<(N + 63) / 64, 256, 0, ns::as_stream(stream)>>>(X_dev, ld, M, N, out_dev);
   NS_LAUNCH_CHECK();
   return NS_OK;
 }
