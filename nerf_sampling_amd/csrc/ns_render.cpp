@@ -36,6 +36,8 @@ int64_t ns_render_workspace_bytes(int64_t R, int N) {
 int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   NS_REQUIRE(a, "null args");
   NS_REQUIRE(a->depthnet && a->nerf, "both networks are required");
+  if (a->o_dev == nullptr ? (a->row1 == a->row0 || a->W == 0) : a->R == 0) return NS_OK;  // nothing to render
+  if (a->o_dev == nullptr && a->H == 0 && a->R == 0) return NS_OK;
   NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
   int N = a->mode == NS_MODE_DEPTH_ONLY ? 1 : a->N;
   NS_REQUIRE(N >= 1, "bad sample count");
@@ -88,6 +90,7 @@ int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf) {
 
 int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   NS_REQUIRE(a && a->coarse, "null args / coarse network");
+  if (a->o_dev == nullptr ? (a->row1 == a->row0 || a->W == 0) : a->R == 0) return NS_OK;  // nothing to render
   NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
   NS_REQUIRE(a->Nc >= 3 && a->Nf >= 0, "needs at least 3 coarse samples");
   int64_t R = a->R;

@@ -361,6 +361,13 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     a = _lib.RenderArgs()
     a.depthnet, a.nerf = depthnet.handle, nerf.handle
     keep = []
+    if rays is not None and rays[0].shape[0] == 0:     # empty batch: nothing to launch
+        dev0, n0 = rays[0].device, (1 if mode == "depth_only" else int(n_samples))
+        out = {"rgb": torch.empty((0, 3), device=dev0), "disp": torch.empty((0,), device=dev0)}
+        if extras:
+            out.update(z=torch.empty((0, n0), device=dev0), weights=torch.empty((0, 0 if n0 == 1 else n0), device=dev0),
+                       pts=torch.empty((0, n0, 3), device=dev0))
+        return out
     if rays is not None:
         o, d, v = (_dev(t, n) for t, n in zip(rays, ("rays_o", "rays_d", "viewdirs")))
         keep += [o, d, v]
