@@ -1,0 +1,57 @@
+"""Two ranks on the one GPU of the test box (gloo transport, CUDA tensors): the real HIP row renderer
+through FrameRenderer -- the N > 1 code path of bench.py, minus RCCL itself."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from conftest import _make_modules
+        from nerf_sampling_amd import synthetic
+        from nerf_sampling_amd.parallel import FrameRenderer, hip_row_renderer
+
+        torch.cuda.set_device(0)
+        m = _make_modules("tiny_synth")
+        H, W = 50, 40                                    # 50 rows over 2 ranks: 25 + 25; over 3 would be uneven
+        _, K = synthetic.blender_intrinsics(H, W)
+        fr = FrameRenderer(H, W, hip_row_renderer(m["depth"].packed("f32"), m["fine"].packed("f32"), H, W, K, 16, "uniform",
+                                                  0.1, device="cuda:0"), "cuda:0")
+        for k, theta in enumerate((15.0, 200.0)):
+            rgb, disp = fr.render(synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4])
+            np.savez(os.path.join(out_dir, f"r{rank}_f{k}.npz"), rgb=rgb.cpu().numpy(), disp=disp.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_assemble_the_single_process_frame(tmp_path, gpu_modules):
+    import torch.multiprocessing as mp
+
+    from nerf_sampling_amd import ops, synthetic
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = gpu_modules("tiny_synth")
+    H, W = 50, 40
+    _, K = synthetic.blender_intrinsics(H, W)
+    for k, theta in enumerate((15.0, 200.0)):
+        full = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                        camera=(H, W, K, synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4], 0, H),
+                                        n_samples=16, mode="uniform", std=0.1)
+        for r in range(2):
+            got = np.load(os.path.join(str(tmp_path), f"r{r}_f{k}.npz"))
+            np.testing.assert_array_equal(got["rgb"].reshape(-1, 3), full["rgb"].cpu().numpy())   # bit exact
+            np.testing.assert_array_equal(got["disp"].reshape(-1), full["disp"].cpu().numpy())
