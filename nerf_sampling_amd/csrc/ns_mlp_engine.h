@@ -38,7 +38,7 @@ constexpr int kChunkBytes = 1024;
 constexpr int kSlabChunks = 16;
 constexpr int kSlabBytes = kChunkBytes * kSlabChunks;
 constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (read-ahead), in flight, being issued
-constexpr int kFragDepth = 4;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
+constexpr int kFragDepth = 2;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -57,17 +57,31 @@ struct MmaBF16 {
   static constexpr int CPB = 2;
   static constexpr int kElemBytes = 2;
   struct Block { bf16x8 v[2]; };
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // one dword = two consecutive features.  hipcc (ROCm 7.2) lowers a {(__bf16)a, (__bf16)b} pair to two
+  // single-value v_cvt_pk_bf16_f32 + a v_perm_b32; the packed form is ONE instruction (RNE, NaN-preserving).
+  // ReLU on the packed pair is a signed 16-bit max with 0 (sign-magnitude floats: negative <=> negative int16).
+  template <bool RELU>
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 ab = {a, b};
+    uint32_t r = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, bf16x2));   // one v_cvt_pk_bf16_f32
+    if constexpr (RELU) {
+      s16x2 q = __builtin_bit_cast(s16x2, r);
+      q = __builtin_elementwise_max(q, (s16x2)(0));
+      r = __builtin_bit_cast(uint32_t, q);
+    }
+    return r;
+  }
+  template <bool RELU = false>
   __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { b.v[0][j] = (__bf16)x[j]; b.v[1][j] = (__bf16)x[8 + j]; }
-  }
-  __device__ static __forceinline__ void relu_packed(Block& b) {
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-#pragma unroll
     for (int i = 0; i < 2; ++i) {
-      s16x8 v = __builtin_bit_cast(s16x8, b.v[i]);
-      v = __builtin_elementwise_max(v, (s16x8)(0));
-      b.v[i] = __builtin_bit_cast(bf16x8, v);
+      u32x4 w = {pack2<RELU>(x[8 * i], x[8 * i + 1]), pack2<RELU>(x[8 * i + 2], x[8 * i + 3]),
+                 pack2<RELU>(x[8 * i + 4], x[8 * i + 5]), pack2<RELU>(x[8 * i + 6], x[8 * i + 7])};
+      b.v[i] = __builtin_bit_cast(bf16x8, w);
     }
   }
   using AFrag = bf16x8;
@@ -82,9 +96,11 @@ struct MmaF16 {
   static constexpr int CPB = 2;
   static constexpr int kElemBytes = 2;
   struct Block { f16x8 v[2]; };
+  template <bool RELU = false>
   __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { b.v[0][j] = (_Float16)x[j]; b.v[1][j] = (_Float16)x[8 + j]; }
+    if constexpr (RELU) relu_packed(b);
   }
   __device__ static __forceinline__ void relu_packed(Block& b) {
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -107,9 +123,10 @@ struct MmaF32 {
   static constexpr int CPB = 4;
   static constexpr int kElemBytes = 4;
   struct Block { float v[16]; };
+  template <bool RELU = false>
   __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) b.v[j] = x[j];
+    for (int j = 0; j < 16; ++j) b.v[j] = RELU ? fmaxf(x[j], 0.0f) : x[j];
   }
   __device__ static __forceinline__ void relu_packed(Block&) {}
   using AFrag = f32x4;
@@ -162,13 +179,14 @@ struct Pipe {
   AFrag f[kFragDepth];  // fragments of the next kFragDepth chunks
 
   __device__ __forceinline__ void issue() {
-    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + lane * 16;
-    char* dst = lds + issue_slot * kSlabBytes;
+    // wave-uniform part of the address in SGPRs, per-lane part a constant 32-bit offset (lane * 16)
+    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
+    char* dst = lds + issue_slot * kSlabBytes + wave * kChunkBytes;
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
-      const int chunk = i * NWAVES + wave;
-      __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src + chunk * kChunkBytes),
-                                       NS_LDS_PTR(dst + chunk * kChunkBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src + i * NWAVES * kChunkBytes + lane_off),
+                                       NS_LDS_PTR(dst + i * NWAVES * kChunkBytes), 16, 0, 0);
     }
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
@@ -298,21 +316,13 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
   static_for<NBO>([&](auto nb_) {
     constexpr int nb = decltype(nb_)::value;
     float x[16];
-    // 16-bit operands: ReLU is applied AFTER packing as a signed 16-bit max with 0 on the pairs
-    // (sign-magnitude floats: negative <=> negative int16), half the VALU work of 16 v_max_f32
-    constexpr bool kPackedRelu = (ACT == kRelu) && (M::kElemBytes == 2);
-#ifdef NS_ABLATE_EPILOGUE
-    if (nb > 0) return;
-#endif
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = acc[nb][r];
-      if constexpr (ACT == kRelu && !kPackedRelu) v = fmaxf(v, 0.0f);
       if constexpr (ACT == kLeaky) v = v > 0.0f ? v : 0.01f * v;
       x[r] = v;
     }
-    M::from_f32(out[nb], x);
-    if constexpr (kPackedRelu) M::relu_packed(out[nb]);
+    M::template from_f32<ACT == kRelu>(out[nb], x);
   });
 }
 
