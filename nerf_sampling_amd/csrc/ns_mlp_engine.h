@@ -96,19 +96,28 @@ struct MmaF16 {
   static constexpr int CPB = 2;
   static constexpr int kElemBytes = 2;
   struct Block { f16x8 v[2]; };
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  template <bool RELU>
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 ab = {a, b};
+    uint32_t r = __builtin_bit_cast(uint32_t, __builtin_convertvector(ab, f16x2));
+    if constexpr (RELU) {
+      s16x2 q = __builtin_bit_cast(s16x2, r);
+      q = __builtin_elementwise_max(q, (s16x2)(0));
+      r = __builtin_bit_cast(uint32_t, q);
+    }
+    return r;
+  }
   template <bool RELU = false>
   __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { b.v[0][j] = (_Float16)x[j]; b.v[1][j] = (_Float16)x[8 + j]; }
-    if constexpr (RELU) relu_packed(b);
-  }
-  __device__ static __forceinline__ void relu_packed(Block& b) {
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-#pragma unroll
     for (int i = 0; i < 2; ++i) {
-      s16x8 v = __builtin_bit_cast(s16x8, b.v[i]);
-      v = __builtin_elementwise_max(v, (s16x8)(0));
-      b.v[i] = __builtin_bit_cast(f16x8, v);
+      u32x4 w = {pack2<RELU>(x[8 * i], x[8 * i + 1]), pack2<RELU>(x[8 * i + 2], x[8 * i + 3]),
+                 pack2<RELU>(x[8 * i + 4], x[8 * i + 5]), pack2<RELU>(x[8 * i + 6], x[8 * i + 7])};
+      b.v[i] = __builtin_bit_cast(f16x8, w);
     }
   }
   using AFrag = f16x8;
