@@ -38,7 +38,10 @@ constexpr int kChunkBytes = 1024;
 constexpr int kSlabChunks = 16;
 constexpr int kSlabBytes = kChunkBytes * kSlabChunks;
 constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (read-ahead), in flight, being issued
-constexpr int kFragDepth = 2;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
+#ifndef NS_FRAG_DEPTH
+#define NS_FRAG_DEPTH 2
+#endif
+constexpr int kFragDepth = NS_FRAG_DEPTH;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -260,13 +263,9 @@ struct Pipe {
   // Open the next slab: its first kFragDepth fragments are already in registers.
   __device__ __forceinline__ void begin_slab() {
     wait_vm<LPW>();                               // my pieces of the slab AFTER this one have landed
-#ifndef NS_ABLATE_BARRIER
     __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
-#endif
     asm volatile("" ::: "memory");
-#ifndef NS_ABLATE_DMA
     issue();                                      // refill the slot the previous slab occupied
-#endif
     cur = lds_off + read_slot * kSlabBytes + lane * 16;
     read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
     nxt = lds_off + read_slot * kSlabBytes + lane * 16;

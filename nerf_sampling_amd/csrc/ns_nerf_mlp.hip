@@ -11,7 +11,12 @@ namespace {
 
 using namespace nsmlp;
 
-constexpr int kLag = 4;  // slabs the trailing half of an 8-wave workgroup runs behind (half a 256-wide layer)
+#ifndef NS_LAG
+#define NS_LAG 0
+#endif
+// slabs the trailing half of an 8-wave workgroup runs behind the leading half.  Same-box interleaved A/B
+// (round 1): LAG 0 = 32.8 ms, LAG 2 = 33.8 ms, LAG 4 = 33.9 ms -> no stagger.
+constexpr int kLag = NS_LAG;
 
 struct NerfArgs {
   const char* stream;
