@@ -41,6 +41,10 @@ def build_modules(scene_name, device):
     fine = NeRF(D=cfg["fine"]["D"], W=cfg["fine"]["W"], input_ch=63, input_ch_views=27, output_ch=5, skips=[4],
                 use_viewdirs=True)
     fine.load_state_dict(params["fine"])
+    if os.environ.get("NS_BENCH_ZERO_NERF"):   # diagnostic only: all-zero MLP operands (is the kernel power-limited?)
+        with torch.no_grad():
+            for p_ in fine.parameters():
+                p_.zero_()
     n, w = cfg["depth"]["n_layers"], cfg["depth"]["width"]
     dn = DepthNet(hidden_sizes=[w] * n, cat_hidden_sizes=[w] * n, sphere_radius=2.0)
     dn.load_state_dict(params["depth"])

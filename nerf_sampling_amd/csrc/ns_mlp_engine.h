@@ -35,13 +35,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kChunkBytes = 1024;
-constexpr int kSlabChunks = 16;
+#ifndef NS_SLAB_CHUNKS
+#define NS_SLAB_CHUNKS 16
+#endif
+constexpr int kSlabChunks = NS_SLAB_CHUNKS;
 constexpr int kSlabBytes = kChunkBytes * kSlabChunks;
 constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (read-ahead), in flight, being issued
 #ifndef NS_FRAG_DEPTH
 #define NS_FRAG_DEPTH 2
 #endif
-constexpr int kFragDepth = NS_FRAG_DEPTH;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
+constexpr int kFragDepth = NS_FRAG_DEPTH;
+#ifndef NS_OB_GROUP
+#define NS_OB_GROUP 1
+#endif
+constexpr int kObGroup = NS_OB_GROUP;       // output blocks in flight in the output-block-major layers (layer_ob)   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -172,8 +179,9 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 // MI355X_MICROARCH.md "Two waves per SIMD", item 9) LAG slabs behind the first half, so that one
 // partner's layer epilogue / tile prologue (VALU, global loads) runs under the other's MFMAs instead
 // of both leaving the matrix pipe idle at once.  It costs LAG more ring slots.
-template <class M, int NWAVES, int LAG = 0>
+template <class M, int NWAVES, int LAG = 0, int DEPTH = kFragDepth>
 struct Pipe {
+  static constexpr int kDepth = DEPTH;   // A fragments in flight (LDS read-ahead, in chunks)
   using AFrag = typename M::AFrag;
   static constexpr int LPW = kSlabChunks / NWAVES;  // DMA instructions per wave per slab
   static constexpr int RING = kRingBase + LAG;
@@ -188,7 +196,7 @@ struct Pipe {
   uint32_t lds_off;     // LDS byte address of the ring base
   uint32_t cur;         // this lane's LDS byte address in the open slab (chunk c at +c*1024)
   uint32_t nxt;         // ... and in the following one
-  AFrag f[kFragDepth];  // fragments of the next kFragDepth chunks
+  AFrag f[DEPTH];       // fragments of the next DEPTH chunks
 
   __device__ __forceinline__ void issue() {
     // wave-uniform part of the address in SGPRs, per-lane part a constant 32-bit offset (lane * 16)
@@ -209,8 +217,8 @@ struct Pipe {
   // the compiler's own counter bookkeeping exact, so its LDS waits stay counted (lgkmcnt(N > 0)).
   template <int N>
   __device__ static __forceinline__ void wait_vm() {
-    static_assert(N >= 0 && N < 16, "unexpected DMA count");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | N);
+    static_assert(N >= 0 && N < 64, "unexpected DMA count");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
   }
 
   // A-fragment read: a plain LDS load (ds_read_b128 from a lane-linear image, conflict-free).  Measured
@@ -232,7 +240,7 @@ struct Pipe {
     lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
     nxt = lds_off + lane * 16;                    // slab 0 is "the following slab" until it is opened
     cur = nxt;
-    static_for<kFragDepth>([&](auto i_) { load<decltype(i_)::value * kChunkBytes>(f[decltype(i_)::value], nxt); });
+    static_for<DEPTH>([&](auto i_) { load<decltype(i_)::value * kChunkBytes>(f[decltype(i_)::value], nxt); });
     if constexpr (LAG > 0) {
       if (wave >= NWAVES / 2) {                   // trailing half: sit out the first LAG slabs
 #pragma unroll 1
@@ -334,6 +342,120 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
   });
 }
 
+// ---- output-block-major layers ("ob" stream layout) ---------------------------------------------
+// The k-major consume<>() above finishes all NBO output blocks of a layer at the same MFMA, so the
+// bias loads and f32 -> 16-bit conversions of a whole layer (about one VALU op per MFMA) come in one
+// burst -- and because every wave of the workgroup meets at the same slab barriers, the two waves of a
+// SIMD burst TOGETHER and the matrix pipe idles.  Here a layer is walked one 32-feature output block
+// at a time (all K chunks of block nb, then block nb+1; the stream is packed in that order by
+// ns_pack.hip layout 1): only one block's accumulators are live, and the conversion of block nb is
+// issued piecewise between the MFMAs of block nb+1, so the VALU work hides under the matrix pipe of
+// the SAME wave.  T sample tiles per wave share every A fragment (T = 2: half the LDS reads, DMA
+// pieces and barriers per MFMA, at one wave per SIMD).
+
+// op(P, frag) is called for chunk P = 0..TOTAL-1 of the stream, in order, with the chunk's A fragment.
+template <int TOTAL, class PipeT, class F>
+__device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
+  constexpr int SLABS = (TOTAL + kSlabChunks - 1) / kSlabChunks;
+  static_for<SLABS>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int USED = (TOTAL - s * kSlabChunks) < kSlabChunks ? (TOTAL - s * kSlabChunks) : kSlabChunks;
+    static_assert(USED % PipeT::kDepth == 0 && USED >= PipeT::kDepth, "fragment pipeline needs USED % depth == 0");
+    pipe.begin_slab();
+    static_for<USED>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth]);
+      if constexpr (p + PipeT::kDepth < USED)
+        pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
+      else
+        pipe.template load<(p + PipeT::kDepth - USED) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.nxt);
+    });
+  });
+}
+__host__ __device__ constexpr int ob_layer_slabs(int cpb, int nbo, int nkb) {
+  return (nbo * nkb * cpb + kSlabChunks - 1) / kSlabChunks;
+}
+
+// dword j (features 2j, 2j+1 of the lane's 16) of a 16-bit block from its fp32 accumulator
+template <class M, bool RELU, int J>
+__device__ __forceinline__ void convert_piece(typename M::Block& out, const f32x16& c) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, out.v[J / 4]);
+  w[J % 4] = M::template pack2<RELU>(c[2 * J], c[2 * J + 1]);
+  out.v[J / 4] = __builtin_bit_cast(typename M::AFrag, w);
+}
+// the G blocks layer_ob() left unconverted: out[t][NBO - G + g] = act(last[g][t])
+template <class M, bool RELU, int T, int G, int NBO, class OutT>
+__device__ __forceinline__ void convert_last(OutT& out, const f32x16 (&last)[G][T]) {
+  static_for<G>([&](auto g_) {
+    static_for<T>([&](auto t_) {
+      static_for<8>([&](auto j_) {
+        convert_piece<M, RELU, decltype(j_)::value>(out[decltype(t_)::value][NBO - G + decltype(g_)::value],
+                                                    last[decltype(g_)::value][decltype(t_)::value]);
+      });
+    });
+  });
+}
+
+__device__ __forceinline__ f32x16 load_bias_block(const float* bias_lds, int nb, int h) {
+  const f32x4* b = reinterpret_cast<const f32x4*>(bias_lds + nb * 32 + h * 16);
+  f32x16 r;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 v = b[g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[4 * g + e] = v[e];
+  }
+  return r;
+}
+
+// One layer, G output blocks in flight (G independent MFMA accumulation chains per tile):
+//   out[t][nb] = act(bias[nb] + sum_kb W[nb, kb] . in(t, kb))   for nb < NBO - G;
+// the LAST group of G blocks is left unconverted in last[g][t] (heads read it raw; hidden layers
+// convert_last() it).  in(t_, kb_) -> const Block& with compile-time tile / K-block indices.
+// Stream order (ns_pack.hip layer_ob): for each group of G blocks, for each K chunk, the G blocks' chunks.
+template <class M, int T, int G, int NBO, int NKB, bool RELU, class PipeT, class OutT, class InF>
+__device__ __forceinline__ void layer_ob(PipeT& pipe, const float* bias_lds, int h, OutT& out, f32x16 (&last)[G][T],
+                                         InF&& in) {
+  static_assert(NBO % G == 0, "output blocks must come in whole groups");
+  constexpr int CH = NKB * M::CPB;                 // K chunks per output block
+  constexpr int STEPS = G * CH;                    // stream chunks per group
+  constexpr int PIECES = 8 * T * G;                // conversion pieces of one finished group
+  constexpr int PPS = (PIECES + STEPS - 1) / STEPS;
+  constexpr int CONV_END = (PIECES + PPS - 1) / PPS;   // step of the next group by which the conversion is done
+  constexpr int BIAS_AT = (STEPS - 4 * G) > CONV_END ? (STEPS - 4 * G) : (STEPS - 1);  // next group's bias fetch
+  f32x16 c[2][G][T];                               // accumulators: group parity x block in group x tile
+  static_for<G>([&](auto g_) {
+    static_for<T>([&](auto t_) { c[0][decltype(g_)::value][decltype(t_)::value] = load_bias_block(bias_lds, decltype(g_)::value, h); });
+  });
+  stream_chunks<(NBO / G) * STEPS>(pipe, [&](auto P_, const typename M::AFrag& frag) {
+    constexpr int P = decltype(P_)::value;
+    constexpr int gb = P / STEPS, step = P % STEPS, kc = step / G, g = step % G, par = gb & 1;
+    static_for<T>([&](auto t_) {
+      M::template mma<kc % M::CPB>(c[par][g][decltype(t_)::value], frag, in(t_, std::integral_constant<int, kc / M::CPB>{}));
+    });
+    if constexpr (gb > 0) {                        // conversion of the previous group under this group's MFMAs
+      static_for<PPS>([&](auto i_) {
+        constexpr int piece = step * PPS + decltype(i_)::value;
+        if constexpr (piece < PIECES) {
+          constexpr int j = piece / (T * G), t = piece % T, gg = (piece % (T * G)) / T;
+          convert_piece<M, RELU, j>(out[t][(gb - 1) * G + gg], c[par ^ 1][gg][t]);
+        }
+      });
+    }
+    if constexpr (step == BIAS_AT && (gb + 1) * G < NBO) {
+      static_for<G>([&](auto g_) {
+        static_for<T>([&](auto t_) {
+          c[par ^ 1][decltype(g_)::value][decltype(t_)::value] = load_bias_block(bias_lds, (gb + 1) * G + decltype(g_)::value, h);
+        });
+      });
+    }
+  });
+  static_for<G>([&](auto g_) {
+    static_for<T>([&](auto t_) { last[decltype(g_)::value][decltype(t_)::value] = c[(NBO / G - 1) & 1][decltype(g_)::value][decltype(t_)::value]; });
+  });
+}
+
 // ---- positional-encoding slots -------------------------------------------------------------------
 // Lane half h = 0 evaluates sines, h = 1 cosines of the same argument (cos x = sin(x + pi/2)),
 // so both halves run the same instruction stream.
@@ -404,6 +526,25 @@ __device__ __forceinline__ void embed3(typename M::Block (&out)[NBLK], const flo
       } else {
         x[q] = 0.0f;
       }
+    });
+    M::from_f32(out[b], x);
+  });
+}
+
+__host__ __device__ inline int embed3_col(int k, int L);
+
+// slot values for a pre-embedded input row (NeRF.forward on [M,90])
+template <class M, int L, int NBLK>
+__device__ __forceinline__ void gather3(typename M::Block (&out)[NBLK], const float* row, int h) {
+  static_for<NBLK>([&](auto b_) {
+    constexpr int b = decltype(b_)::value;
+    float x[16];
+    static_for<16>([&](auto q_) {
+      constexpr int q = decltype(q_)::value;
+      constexpr int k0 = 32 * b + (q & 3) + 8 * (q >> 2);  // + 4h
+      const int c0 = embed3_col(k0, L), c1 = embed3_col(k0 + 4, L);
+      const int c = h ? c1 : c0;
+      x[q] = c >= 0 ? row[c] : 0.0f;
     });
     M::from_f32(out[b], x);
   });

@@ -11,12 +11,6 @@ namespace {
 
 using namespace nsmlp;
 
-#ifndef NS_LAG
-#define NS_LAG 0
-#endif
-// slabs the trailing half of an 8-wave workgroup runs behind the leading half.  Same-box interleaved A/B
-// (round 1): LAG 0 = 32.8 ms, LAG 2 = 33.8 ms, LAG 4 = 33.9 ms -> no stagger.
-constexpr int kLag = NS_LAG;
 
 struct NerfArgs {
   const char* stream;
@@ -35,23 +29,6 @@ struct NerfArgs {
   int N;                  // samples per ray
   float* raw;             // [S,4]
 };
-
-// slot values for a pre-embedded input row (NeRF.forward on [M,90])
-template <class M, int L, int NBLK>
-__device__ __forceinline__ void gather3(typename M::Block (&out)[NBLK], const float* row, int h) {
-  static_for<NBLK>([&](auto b_) {
-    constexpr int b = decltype(b_)::value;
-    float x[16];
-    static_for<16>([&](auto q_) {
-      constexpr int q = decltype(q_)::value;
-      constexpr int k0 = 32 * b + (q & 3) + 8 * (q >> 2);  // + 4h
-      const int c0 = embed3_col(k0, L), c1 = embed3_col(k0 + 4, L);
-      const int c = h ? c1 : c0;
-      x[q] = c >= 0 ? row[c] : 0.0f;
-    });
-    M::from_f32(out[b], x);
-  });
-}
 
 template <class M, int NB, int NWAVES, int LAG, bool PRECISE_TRIG, bool EMBEDDED>
 __global__ void __launch_bounds__(NWAVES * 64)
@@ -189,15 +166,17 @@ int dispatch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
   switch (net->dtype) {
     case NS_DTYPE_F32:
       return NB == 8 ? launch<MmaF32, 8, 4, 0, true, EMB>(net, a, stream) : launch<MmaF32, 4, 4, 0, true, EMB>(net, a, stream);
-    case NS_DTYPE_BF16:
-      return NB == 8 ? launch<MmaBF16, 8, EMB ? 4 : 8, EMB ? 0 : kLag, false, EMB>(net, a, stream) : launch<MmaBF16, 4, 8, kLag, false, EMB>(net, a, stream);
-    case NS_DTYPE_F16:
-      return NB == 8 ? launch<MmaF16, 8, EMB ? 4 : 8, EMB ? 0 : kLag, false, EMB>(net, a, stream) : launch<MmaF16, 4, 8, kLag, false, EMB>(net, a, stream);
+    default:   // 16-bit handles are packed output-block-major and run in ns_nerf_mlp_ob.hip
+      break;
   }
   return NS_E_UNSUPPORTED;
 }
 
 }  // namespace
+
+int ns_nerf_forward_ob(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
+                       const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
+                       float* raw_dev, hipStream_t stream);
 
 extern "C" {
 
@@ -210,6 +189,9 @@ int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_
   NS_REQUIRE(raw_dev && viewdirs_dev, "null pointer");
   NS_REQUIRE(pts_dev || (o_dev && d_dev && z_dev), "need pts or (o, d, z)");
   NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  if (net->layout > 0)
+    return ns_nerf_forward_ob(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
+                              ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
@@ -226,6 +208,9 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
   if (M == 0) return NS_OK;
   NS_REQUIRE(x_dev && raw_dev, "null pointer");
   NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  if (net->layout > 0)
+    return ns_nerf_forward_ob(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
+                              ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;

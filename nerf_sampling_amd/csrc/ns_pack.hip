@@ -50,8 +50,28 @@ struct Builder {
     }
   }
 
-  // One K-segment: rows of Wm ([out_f, in_f] row-major) as NBO output blocks, NBLK input blocks
-  // whose virtual feature k maps to reference column colmap(k) (or -1 = zero).
+  // one 1-KiB A-operand chunk: output block nb, input block blk, K sub-step sub
+  void fill_chunk(uint8_t* chunk, const float* Wm, int out_f, int in_f, int nb, int blk, int sub,
+                  const std::function<int(int)>& colmap) const {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = lane & 31, h = lane >> 5;
+      const int n = 32 * nb + r;
+      for (int e = 0; e < epc; ++e) {
+        const int q = epc * sub + e;
+        const int k = 32 * blk + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const int col = colmap(k);
+        float v = 0.0f;
+        if (n < out_f && col >= 0) {
+          if (col >= in_f) { std::fprintf(stderr, "ns_pack: column %d out of range %d\n", col, in_f); std::abort(); }
+          v = Wm[static_cast<size_t>(n) * in_f + col];
+        }
+        put(chunk + lane * 16, e, v);
+      }
+    }
+  }
+
+  // Layout 0 (k-major, consume<>()): one K-segment, rows of Wm ([out_f, in_f] row-major) as NBO output
+  // blocks, NBLK input blocks whose virtual feature k maps to reference column colmap(k) (or -1 = zero).
   void segment(const float* Wm, int out_f, int in_f, int nbo, int nblk, const std::function<int(int)>& colmap) {
     const int kps = kSlabChunks / nbo;
     const int chunks = nblk * cpb;
@@ -62,27 +82,31 @@ struct Builder {
       for (int kk = 0; kk < kps; ++kk) {
         const int kc = s * kps + kk;
         if (kc >= chunks) continue;
-        const int blk = kc / cpb, sub = kc % cpb;
-        for (int nb = 0; nb < nbo; ++nb) {
-          uint8_t* chunk = bytes.data() + base + static_cast<size_t>(kk * nbo + nb) * kChunkBytes;
-          for (int lane = 0; lane < 64; ++lane) {
-            const int r = lane & 31, h = lane >> 5;
-            const int n = 32 * nb + r;
-            for (int e = 0; e < epc; ++e) {
-              const int q = epc * sub + e;
-              const int k = 32 * blk + (q & 3) + 8 * (q >> 2) + 4 * h;
-              const int col = colmap(k);
-              float v = 0.0f;
-              if (n < out_f && col >= 0) {
-                if (col >= in_f) { std::fprintf(stderr, "ns_pack: column %d out of range %d\n", col, in_f); std::abort(); }
-                v = Wm[static_cast<size_t>(n) * in_f + col];
-              }
-              put(chunk + lane * 16, e, v);
-            }
-          }
-        }
+        for (int nb = 0; nb < nbo; ++nb)
+          fill_chunk(bytes.data() + base + static_cast<size_t>(kk * nbo + nb) * kChunkBytes, Wm, out_f, in_f, nb,
+                     kc / cpb, kc % cpb, colmap);
       }
     }
+  }
+
+  // Layout 1 (output-block-major, layer_ob<>()): a whole layer = for each output block, the chunks of all
+  // its K-segments in order; padded to a slab boundary.
+  struct Seg { int nblk; std::function<int(int)> colmap; };
+  int ob_group = 1;   // output blocks in flight (G of layer_ob<>)
+  void layer_ob(const float* Wm, int out_f, int in_f, int nbo, const std::vector<Seg>& segs) {
+    const size_t base = bytes.size();
+    const int G = nbo % ob_group == 0 ? ob_group : 1;
+    size_t n = 0;
+    for (int gb = 0; gb < nbo / G; ++gb)
+      for (const Seg& sg : segs)
+        for (int kc = 0; kc < sg.nblk * cpb; ++kc)
+          for (int g = 0; g < G; ++g) {
+            bytes.resize(base + (n + 1) * kChunkBytes, 0);
+            fill_chunk(bytes.data() + base + n * kChunkBytes, Wm, out_f, in_f, gb * G + g, kc / cpb, kc % cpb, sg.colmap);
+            ++n;
+          }
+    const size_t slabs = (n + kSlabChunks - 1) / kSlabChunks;
+    bytes.resize(base + slabs * kSlabBytes, 0);
   }
 
   void add_bias(const float* b, int out_f, int nbo) {
@@ -128,34 +152,59 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   Builder bl(dtype);
   auto ident = [](int k) { return k; };
   auto xcol = [](int k) { return nsmlp::embed3_col(k, 10); };
-  // layer 0: 63 -> W
-  bl.add_bias(b[0], W, NB);
-  bl.segment(w[0], W, 63, NB, 2, xcol);
-  for (int l = 1; l < D; ++l) {
-    bl.add_bias(b[l], W, NB);
-    if (l - 1 == skip) {  // input = cat[x(63), h(W)]  (run_nerf_helpers.py:118)
-      bl.segment(w[l], W, W + 63, NB, 2, xcol);
-      bl.segment(w[l], W, W + 63, NB, NB, [](int k) { return 63 + k; });
-    } else {
-      bl.segment(w[l], W, W, NB, NB, ident);
+  const int layout = dtype == NS_DTYPE_F32 ? 0 : nsmlp::kObGroup;   // 0 = k-major; G > 0 = output-block-major, G in flight
+  bl.ob_group = layout > 0 ? layout : 1;
+  if (layout == 0) {
+    // layer 0: 63 -> W
+    bl.add_bias(b[0], W, NB);
+    bl.segment(w[0], W, 63, NB, 2, xcol);
+    for (int l = 1; l < D; ++l) {
+      bl.add_bias(b[l], W, NB);
+      if (l - 1 == skip) {  // input = cat[x(63), h(W)]  (run_nerf_helpers.py:118)
+        bl.segment(w[l], W, W + 63, NB, 2, xcol);
+        bl.segment(w[l], W, W + 63, NB, NB, [](int k) { return 63 + k; });
+      } else {
+        bl.segment(w[l], W, W, NB, NB, ident);
+      }
     }
+    const float* const* wf = w + D;
+    const float* const* bf = b + D;
+    // alpha (W -> 1), feature (W -> W), views ([feature, dirs27] -> W/2), rgb (W/2 -> 3)
+    bl.add_bias(bf[1], 1, 1);
+    bl.segment(wf[1], 1, W, 1, NB, ident);
+    bl.add_bias(bf[0], W, NB);
+    bl.segment(wf[0], W, W, NB, NB, ident);
+    bl.add_bias(bf[2], W / 2, NB / 2);
+    bl.segment(wf[2], W / 2, W + 27, NB / 2, NB, ident);
+    bl.segment(wf[2], W / 2, W + 27, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
+    bl.add_bias(bf[3], 3, 1);
+    bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
+  } else {
+    // same layers, output-block-major (ns_nerf_mlp_ob.hip consumes them in this order)
+    auto hcol = [](int k) { return 63 + k; };
+    bl.add_bias(b[0], W, NB);
+    bl.layer_ob(w[0], W, 63, NB, {{2, xcol}});
+    for (int l = 1; l < D; ++l) {
+      bl.add_bias(b[l], W, NB);
+      if (l - 1 == skip) bl.layer_ob(w[l], W, W + 63, NB, {{2, xcol}, {NB, hcol}});
+      else bl.layer_ob(w[l], W, W, NB, {{NB, ident}});
+    }
+    const float* const* wf = w + D;
+    const float* const* bf = b + D;
+    bl.add_bias(bf[1], 1, 1);
+    bl.layer_ob(wf[1], 1, W, 1, {{NB, ident}});
+    bl.add_bias(bf[0], W, NB);
+    bl.layer_ob(wf[0], W, W, NB, {{NB, ident}});
+    bl.add_bias(bf[2], W / 2, NB / 2);
+    bl.layer_ob(wf[2], W / 2, W + 27, NB / 2,
+                {{NB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; }}});
+    bl.add_bias(bf[3], 3, 1);
+    bl.layer_ob(wf[3], 3, W / 2, 1, {{NB / 2, ident}});
   }
-  const float* const* wf = w + D;
-  const float* const* bf = b + D;
-  // alpha (W -> 1), feature (W -> W), views ([feature, dirs27] -> W/2), rgb (W/2 -> 3)
-  bl.add_bias(bf[1], 1, 1);
-  bl.segment(wf[1], 1, W, 1, NB, ident);
-  bl.add_bias(bf[0], W, NB);
-  bl.segment(wf[0], W, W, NB, NB, ident);
-  bl.add_bias(bf[2], W / 2, NB / 2);
-  bl.segment(wf[2], W / 2, W + 27, NB / 2, NB, ident);
-  bl.segment(wf[2], W / 2, W + 27, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
-  bl.add_bias(bf[3], 3, 1);
-  bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
 
   ns_weights* h = new ns_weights();
   std::memset(h, 0, sizeof(*h));
-  h->kind = NS_KIND_NERF; h->dtype = dtype; h->width = W; h->depth = D; h->skip = skip;
+  h->kind = NS_KIND_NERF; h->dtype = dtype; h->width = W; h->depth = D; h->skip = skip; h->layout = layout;
   int rc = finish(bl, h);
   if (rc != NS_OK) { ns_weights_destroy(h); return rc; }
   *out = h;

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build a tuning variant of the library for same-box A/B runs:
+#   tools/build_variant.sh NAME [-DNS_SLAB_CHUNKS=32 ...]   ->  gpurun_ab_NAME.so (select with NS_LIB_PATH)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/nerf_sampling_amd/csrc
+bld=/tmp/ns_variant_$name
+mkdir -p $bld
+flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off $*"
+pids=()
+for f in ns_core.cpp ns_render.cpp; do /opt/rocm/bin/hipcc $flags -x hip -c $src/$f -o $bld/${f%.*}.o & pids+=($!); done
+for f in ns_rays ns_composite ns_pack ns_nerf_mlp ns_depthnet ns_train; do /opt/rocm/bin/hipcc $flags -c $src/$f.hip -o $bld/$f.o & pids+=($!); done
+/opt/rocm/bin/hipcc $flags -mllvm -amdgpu-mfma-vgpr-form -c $src/ns_nerf_mlp_ob.hip -o $bld/ns_nerf_mlp_ob.o & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $bld/*.o -o $root/gpurun_ab_$name.so
+echo built $root/gpurun_ab_$name.so
