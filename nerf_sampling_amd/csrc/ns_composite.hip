@@ -213,6 +213,90 @@ importance_z_kernel(const float* __restrict__ z, const float* __restrict__ w, in
   }
 }
 
+// Same operator, one WAVE per ray with everything but the two lookup tables in registers (Nc <= 64,
+// Nc + Nf <= 64 * NR): the CDF is a wave prefix scan in double (every partial sum of <= 64 floats spanning
+// < 2^29 is exact in double, so the scan order cannot change ATen's sequential result), the sort is a bitonic
+// network over NR registers x 64 lanes (lane exchanges by ds_bpermute-free __shfl_xor, register exchanges in
+// place) -- no block barrier and no serial lane-0 loop.  The LDS version above stays for longer rows.
+template <int NR>
+__global__ void __launch_bounds__(256)
+importance_z_wave_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t R, int Nc, int Nf,
+                         const float* __restrict__ u, float* __restrict__ out) {
+  __shared__ float cdf_all[4][64], bins_all[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* cdf_s = cdf_all[wv];
+  float* bins_s = bins_all[wv];
+  const int Nb = Nc - 1, tot = Nc + Nf;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < R; r += nwaves) {
+    const float zk = lane < Nc ? z[r * Nc + lane] : 0.0f;
+    const float zn = __shfl_down(zk, 1, 64);
+    // pdf_k = w[k + 1] + 1e-5 for k < Nb - 1; sum by the same xor butterfly as build_cdf()
+    const float v = lane < Nb - 1 ? w[r * Nc + 1 + lane] + 1e-5f : 0.0f;
+    float part = v;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) part += __shfl_xor(part, m, 64);
+    double run = lane < Nb - 1 ? static_cast<double>(v / part) : 0.0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const double up = __shfl_up(run, m, 64);
+      if (lane >= m) run += up;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous ray's lookups are done
+    if (lane < Nb) bins_s[lane] = 0.5f * (zn + zk);
+    if (lane == 0) cdf_s[0] = 0.0f;
+    if (lane < Nb - 1) cdf_s[lane + 1] = static_cast<float>(run);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float e[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int i = q * 64 + lane;
+      if (i < Nc) e[q] = zk;                      // only q == 0: Nc <= 64
+      else if (i < tot) {
+        const int sidx = i - Nc;
+        const float uu = u ? u[r * Nf + sidx] : linspace01(Nf, sidx);
+        e[q] = invert_cdf(cdf_s, bins_s, Nb, uu);
+      } else e[q] = __builtin_nanf("");
+    }
+#pragma unroll
+    for (int k = 2; k <= 64 * NR; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        if (j >= 64) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const int pq = q ^ (j >> 6);
+            if (pq > q) {
+              const bool up = (((q * 64 + lane) & k) == 0);
+              const float a = e[q], b = e[pq];
+              const bool swap = up ? sort_less(b, a) : sort_less(a, b);
+              e[q] = swap ? b : a;
+              e[pq] = swap ? a : b;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NR; ++q) {
+            const int idx = q * 64 + lane;
+            const float mine = e[q], other = __shfl_xor(mine, j, 64);
+            const bool up = ((idx & k) == 0), lower = ((lane & j) == 0);
+            // the lower index of the pair keeps the smaller value when sorting up
+            const bool take_min = (up == lower);
+            const bool other_less = sort_less(other, mine), mine_less = sort_less(mine, other);
+            e[q] = take_min ? (other_less ? other : mine) : (mine_less ? other : mine);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int i = q * 64 + lane;
+      if (i < tot) out[r * tot + i] = e[q];
+    }
+  }
+}
+
 // nerf_utils.py:813-819: argmax over samples (first index on ties, NaN counts as largest)
 __device__ __forceinline__ bool beats(float v, int i, float bv, int bi) {
   if (i == 0x7fffffff) return false;
@@ -320,6 +404,16 @@ int ns_importance_z(const float* z_dev, const float* weights_dev, int64_t R, int
   const int grid = static_cast<int>(R < 256 * 32 ? R : 256 * 32);
   hipStream_t s = ns::as_stream(stream);
   const int tot = Nc + Nf;
+  if (Nc <= 64 && tot <= 256) {   // one wave per ray, registers only
+    int64_t g = ns::cdiv(R, 4);
+    if (g > 256 * 32) g = 256 * 32;
+    const int gi = static_cast<int>(g);
+    if (tot <= 64) importance_z_wave_kernel<1><<<gi, 256, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+    else if (tot <= 128) importance_z_wave_kernel<2><<<gi, 256, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+    else importance_z_wave_kernel<4><<<gi, 256, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
+    NS_LAUNCH_CHECK();
+    return NS_OK;
+  }
   if (tot <= 64) importance_z_kernel<64><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
   else if (tot <= 128) importance_z_kernel<128><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);
   else if (tot <= 256) importance_z_kernel<256><<<grid, 64, 0, s>>>(z_dev, weights_dev, R, Nc, Nf, u_dev, z_out_dev);

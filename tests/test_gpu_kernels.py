@@ -208,6 +208,26 @@ def test_importance_z_and_coarse_z(ops, golden):
     assert (mine[:, 1:] >= mine[:, :-1]).all()
 
 
+@pytest.mark.parametrize("Nc,Nf,random_u", [(64, 128, True), (8, 16, False), (8, 16, True), (32, 64, True),
+                                             (33, 95, False), (64, 192, True), (96, 200, True), (3, 5, False)])
+def test_importance_z_shapes(ops, Nc, Nf, random_u):
+    """Both kernels behind ns_importance_z (one wave per ray in registers for Nc <= 64 and Nc + Nf <= 256, the LDS
+    version beyond) against the oracle, with sorted (deterministic) and unsorted (random u) samples."""
+    gen = torch.Generator().manual_seed(100 * Nc + Nf)
+    R = 257
+    zc = torch.sort(2.0 + 4.0 * torch.rand(R, Nc, generator=gen), -1).values
+    w = torch.rand(R, Nc, generator=gen) ** 3
+    w[5] = 0.0                                      # all mass from the 1e-5 floor
+    u = torch.rand(R, Nf, generator=gen) if random_u else None
+    z_mid = 0.5 * (zc[..., 1:] + zc[..., :-1])
+    ref = torch.sort(torch.cat([zc, O.sample_pdf(z_mid, w[..., 1:-1], Nf, det=True, u=u)], -1), -1).values
+    mine = ops.importance_z(zc.cuda(), w.cuda(), Nf, None if u is None else u.cuda()).cpu()
+    assert mine.shape == (R, Nc + Nf) and torch.isfinite(mine).all()
+    assert (mine[:, 1:] >= mine[:, :-1]).all()
+    err = (mine - ref).abs().numpy()
+    assert np.mean(err > 2e-5) < 5e-3 and np.median(err) < 1e-6
+
+
 def test_argmax_gather(ops):
     gen = torch.Generator().manual_seed(8)
     w = torch.rand(50, 192, generator=gen); z = torch.rand(50, 192, generator=gen); raw = torch.randn(50, 192, 4, generator=gen)

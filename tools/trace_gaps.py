@@ -3,7 +3,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    for k in ("nerf_mlp", "depthnet", "raw2outputs", "place_z", "get_rays", "copyBuffer", "elementwise", "fill"):
+    for k in ("nerf_mlp", "depthnet", "raw2outputs", "place_z", "get_rays", "copyBuffer", "elementwise", "fill", "importance_z", "coarse_z", "sample_pdf", "sort_rows", "points"):
         if k in n: return k
     return n[:24]
 # frames start at get_rays
