@@ -184,7 +184,7 @@ def main():
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (not live);
     # only quoted for the exact workload they were collected on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r01b_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
@@ -215,7 +215,7 @@ def main():
                                    + f", seeded synthetic weights ({args.scene}), spiral render poses of load_blender.py",
                        "rays_per_step": H * W, "samples_per_ray": args.samples,
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
-            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_ob_kernel" if args.dtype != "f32" else "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop},
         }
