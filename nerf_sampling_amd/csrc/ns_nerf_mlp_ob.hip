@@ -67,36 +67,76 @@ nerf_mlp_ob_kernel(NerfObArgs a) {
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
 
+  // Inputs of the NEXT group are fetched right after layer 0 of the current one, by LDS-DMA into a per-wave
+  // staging area (no registers held across the network), so the dependent global loads (sample -> ray -> o, d,
+  // viewdirs) are never waited for at a tile boundary: a lone wave per SIMD has nobody to hide them behind
+  // (ablation without the loads: -6 % kernel time).  Staging layout per wave: [T][10 values][64 lanes] floats;
+  // pts mode: p[0..2], v at 7..9;  (o, d, z) mode: o 0..2, d 3..5, z 6, v 7..9.
+  const uint32_t stage_base = stash_base - static_cast<uint32_t>(lane) * 16u - static_cast<uint32_t>(wave) * (T * 3 * 2048) +
+                              NWAVES * (T * 3 * 2048) + static_cast<uint32_t>(wave) * (T * 10 * 256);
+  auto sample_of = [&](int64_t g, int t, bool& valid) -> int64_t {
+    const int64_t tile = (g * NWAVES + wave) * T + t;
+    int64_t sidx = tile * 32 + (lane & 31);
+    valid = sidx < a.S;
+    return valid ? sidx : a.S - 1;   // clamp: compute on a real sample, mask the store
+  };
+  auto prefetch = [&](int64_t g) {
+    if constexpr (!EMBEDDED) {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        bool valid;
+        const int64_t sidx = sample_of(g, t, valid);
+        const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
+                                              : sidx / a.N;
+        auto put = [&](int slot, const float* src) {
+          __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src),
+                                           NS_LDS_PTR(static_cast<uintptr_t>(stage_base + (t * 10 + slot) * 256)), 4, 0, 0);
+        };
+        if (a.pts) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) put(c, a.pts + sidx * 3 + c);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
+          put(6, a.z + sidx);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+      });
+    }
+  };
+  auto staged = [&](int t, int slot) -> float {
+    return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
+        static_cast<uintptr_t>(stage_base + (t * 10 + slot) * 256 + lane * 4));
+  };
+
   const int64_t n_tiles = (a.S + 31) / 32;
   const int64_t n_groups = (n_tiles + NWAVES * T - 1) / (NWAVES * T);
+  prefetch(blockIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-    int64_t s[T];
-    bool valid[T];
     Block xe[T][2];   // embedded point (63 -> 64 virtual features); registers for layer 0 only
+    asm volatile("" ::: "memory");   // the staged inputs landed several slab steps ago (in-order vmcnt)
     static_for<T>([&](auto t_) {
       Block ve[1];    // embedded view direction (27 -> 32)
       constexpr int t = decltype(t_)::value;
-      const int64_t tile = (g * NWAVES + wave) * T + t;
-      s[t] = tile * 32 + (lane & 31);
-      valid[t] = s[t] < a.S;
-      if (!valid[t]) s[t] = a.S - 1;  // clamp: compute on a real sample, mask the store
       if constexpr (EMBEDDED) {
-        const float* row = a.x90 + s[t] * 90;
+        bool valid;
+        const float* row = a.x90 + sample_of(g, t, valid) * 90;
         gather3<M, 10, 2>(xe[t], row, h);
         gather3<M, 4, 1>(ve, row + 63, h);
       } else {
-        const int64_t ray = s[t] / a.N;
         float p[3], v[3];
         if (a.pts) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) p[c] = a.pts[s[t] * 3 + c];
+          for (int c = 0; c < 3; ++c) p[c] = staged(t, c);
         } else {
-          const float zz = a.z[s[t]];
+          const float zz = staged(t, 6);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) p[c] = a.o[ray * 3 + c] + a.d[ray * 3 + c] * zz;
+          for (int c = 0; c < 3; ++c) p[c] = staged(t, c) + staged(t, 3 + c) * zz;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
+        for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
         embed3<M, false, 10, 2>(xe[t], p, h);
         embed3<M, false, 4, 1>(ve, v, h);
       }
@@ -122,6 +162,9 @@ nerf_mlp_ob_kernel(NerfObArgs a) {
 
     // layer 0: x -> hA
     layer_ob<M, T, G, NB, 2, true>(ring, bias, h, hA, last, in_x); finish_A(); bias += NB * 32;
+    // next group's inputs (clamped to the last sample past the end: loaded, never used); the reads of this group's
+    // staged values are complete (their results fed the embeddings above)
+    prefetch(g + gridDim.x);
     int l = 1;
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     for (; l + 1 < a.D; l += 2) {
@@ -158,7 +201,9 @@ nerf_mlp_ob_kernel(NerfObArgs a) {
     if (h == 0) {
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
-        if (valid[t]) reinterpret_cast<float4*>(a.raw)[s[t]] = make_float4(last1[0][t][0], last1[0][t][1], last1[0][t][2], sigma[t]);
+        bool valid;
+        const int64_t sidx = sample_of(g, t, valid);
+        if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = make_float4(last1[0][t][0], last1[0][t][1], last1[0][t][2], sigma[t]);
       });
     }
   }
@@ -177,7 +222,8 @@ int ob_program_slabs(int NB, int D, int skip) {
 template <class M, int NB, int NWAVES, int T, int G, bool EMB>
 int launch(NerfObArgs& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, NWAVES, 0, NS_OB_DEPTH>::kLdsBytes) +
-                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(NWAVES) * T * 3 * 2048;
+                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(NWAVES) * T * 3 * 2048 +
+                     static_cast<size_t>(NWAVES) * T * 10 * 256;   // ring | bias | embedding stash | input staging
   auto kern = nerf_mlp_ob_kernel<M, NB, NWAVES, T, G, EMB>;
   static bool attr_set = false;
   if (!attr_set) {
