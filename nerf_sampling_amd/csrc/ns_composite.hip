@@ -2,6 +2,7 @@
 // sampling, per-ray argmax.  HBM-bound: every sample is read once (16 B raw + 4 B z) and the
 // per-sample outputs written once; the transmittance product is a wave-level segmented scan.
 #include "ns_common.h"
+#include "ns_composite_ray.h"
 
 namespace {
 
@@ -30,65 +31,35 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
     const int64_t r = it * ray_stride + (int64_t)blockIdx.x * RAYS_PER_BLOCK + threadIdx.x / SW;
     const bool live = r < R;
     float norm = 0.f;
-    if (live) {
-      const float dx = rays_d[r * 3], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
-      norm = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));  // torch.norm: fma chain
-    }
-    float carry = 1.0f;
-    float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_depth = 0.f, s_acc = 0.f;
+    if (live) norm = nscomp::ray_norm(rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]);
+    nscomp::RayAccum A;
     for (int base = 0; base < N; base += SW) {
       const int i = base + sub;
       const bool ok = live && i < N;
-      float alpha = 0.f, zi = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      float zi = 0.f, dist_raw = 0.f, nz = 0.f;
       if (ok) {
         const int64_t e = r * N + i;
-        const float4 q = raw[e];
+        q = raw[e];
         zi = z[e];
-        const float dist = ((i < N - 1) ? z[e + 1] - zi : 1e10f) * norm;
-        float sigma = q.w;
-        if (noise) sigma += noise[e];
-        alpha = 1.0f - expf(-fmaxf(sigma, 0.0f) * dist);
-        if (sigma != sigma) alpha = sigma;  // relu(NaN) is NaN in torch
-        cr = 1.0f / (1.0f + expf(-q.x));
-        cg = 1.0f / (1.0f + expf(-q.y));
-        cb = 1.0f / (1.0f + expf(-q.z));
+        dist_raw = (i < N - 1) ? z[e + 1] - zi : 1e10f;
+        if (noise) nz = noise[e];
       }
-      // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this ray
-      float p = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
-#pragma unroll
-      for (int dlt = 1; dlt < SW; dlt <<= 1) {
-        const float up = __shfl_up(p, dlt, SW);
-        if (sub >= dlt) p *= up;
-      }
-      float excl = __shfl_up(p, 1, SW);
-      if (sub == 0) excl = 1.0f;
-      const float T = carry * excl;
-      const float w = alpha * T;
-      carry = carry * __shfl(p, SW - 1, SW);
+      float alpha, w;
+      nscomp::composite_chunk<SW>(A, ok, sub, q, zi, dist_raw, norm, nz, noise != nullptr, alpha, w);
       if (ok) {
         const int64_t e = r * N + i;
         if (alphas_out) alphas_out[e] = alpha;
         if (weights_out) weights_out[e] = w;
-        s_r += w * cr; s_g += w * cg; s_b += w * cb;
-        s_depth += w * zi;
-        s_acc += w;
       }
     }
-#pragma unroll
-    for (int m = SW >> 1; m > 0; m >>= 1) {
-      s_r += __shfl_xor(s_r, m, SW); s_g += __shfl_xor(s_g, m, SW); s_b += __shfl_xor(s_b, m, SW);
-      s_depth += __shfl_xor(s_depth, m, SW); s_acc += __shfl_xor(s_acc, m, SW);
-    }
+    float disp;
+    nscomp::composite_finish<SW>(A, white_bkgd, disp);
     if (live && sub == 0) {
-      if (white_bkgd) { s_r += 1.0f - s_acc; s_g += 1.0f - s_acc; s_b += 1.0f - s_acc; }
-      if (rgb_out) { rgb_out[r * 3] = s_r; rgb_out[r * 3 + 1] = s_g; rgb_out[r * 3 + 2] = s_b; }
-      if (acc_out) acc_out[r] = s_acc;
-      if (depth_out) depth_out[r] = s_depth;
-      if (disp_out) {
-        const float q = s_depth / (s_acc + 1e-10f);
-        // torch.max(1e-10, q) propagates NaN
-        disp_out[r] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
-      }
+      if (rgb_out) { rgb_out[r * 3] = A.r; rgb_out[r * 3 + 1] = A.g; rgb_out[r * 3 + 2] = A.b; }
+      if (acc_out) acc_out[r] = A.acc;
+      if (depth_out) depth_out[r] = A.depth;
+      if (disp_out) disp_out[r] = disp;
     }
   }
 }

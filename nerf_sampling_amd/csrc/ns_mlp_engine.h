@@ -270,8 +270,12 @@ struct Pipe {
 
   // Open the next slab: its first kFragDepth fragments are already in registers.
   __device__ __forceinline__ void begin_slab() {
+#ifndef NS_EXP_NOWAIT     // NS_EXP_*: timing ablations only (results are wrong)
     wait_vm<LPW>();                               // my pieces of the slab AFTER this one have landed
+#endif
+#ifndef NS_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
+#endif
     asm volatile("" ::: "memory");
     issue();                                      // refill the slot the previous slab occupied
     cur = lds_off + read_slot * kSlabBytes + lane * 16;

@@ -245,6 +245,36 @@ def test_fused_matches_operator_chain(gpu_modules):
     assert torch.equal(torch.cat([top["rgb"], bot["rgb"]]), out["rgb"])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("scene,rows", [("lego_synth", 47), ("tiny_synth", 5)])
+def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scene, rows):
+    """The one-call chain (ns_render_rays_depthnet) on the 16-bit kernels is bit-identical to the operator chain
+    depthnet_forward -> place_samples -> nerf_forward -> raw2outputs, for ragged ray counts and several N."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules(scene)
+    H, W = rows, 47                              # 2209 / 235 rays: ragged last workgroup
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(40.0, -30.0, 4.0)[:3, :4]
+    dn, nf = m["depth"].packed(dtype), m["fine"].packed(dtype)
+    for n in (64, 32, 96):
+        out = ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=n, mode="uniform", std=0.1,
+                                       extras=True)
+        o, d, view = ops.get_rays(H, W, K, c2w)[:3]
+        mean = ops.depthnet_forward(dn, o, d)
+        pts, z = ops.place_samples(o, d, mean, n, "uniform", 0.1)
+        raw = ops.nerf_forward_rays(nf, o, d, z, view)
+        rgb, disp, acc, depth, alphas, weights = ops.raw2outputs(raw, z, d, None, True)
+        assert torch.equal(out["z"], z)
+        assert torch.equal(out["rgb"], rgb) and torch.equal(out["disp"], disp)
+        assert torch.equal(out["weights"], weights)
+    # without per-sample outputs (the benchmark configuration)
+    lean = ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=64, mode="uniform", std=0.1)
+    ref = ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=64, mode="uniform", std=0.1,
+                                   extras=True)
+    assert torch.equal(lean["rgb"], ref["rgb"]) and torch.equal(lean["disp"], ref["disp"])
+
+
 @pytest.mark.parametrize("dtype,min_psnr", [("bf16", 18.0), ("f16", 25.0)])
 def test_full_size_frame_properties(gpu_modules, dtype, min_psnr):
     """BASELINE config 2 size (800x800, DepthNet + 64 samples/ray): size-independent properties of the
