@@ -32,6 +32,9 @@ DEPTHNET_FLOP_PER_RAY = 2 * 3_330_304
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
 
 
+MEASURED_MFMA_CEILING = {"bf16": 1800.0, "f16": None, "f32": 155.0}   # TFLOP/s, see DESIGN.md section 6
+
+
 def build_modules(scene_name, device):
     from nerf_sampling_amd import synthetic
     from nerf_sampling_amd.depth_net import DepthNet
@@ -217,7 +220,10 @@ def main():
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
             "roofline": {"bound": "mfma", "kernel": "nerf_mlp_ob_kernel" if args.dtype != "f32" else "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop},
+                         "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop,
+                         # context, not the contract's peak: what a bare v_mfma_f32_32x32x16 loop whose A and B operands
+                         # change on every MFMA sustains on this part under its power cap (tools/mfma_peak.hip)
+                         "measured_mfma_ceiling": MEASURED_MFMA_CEILING.get(args.dtype)},
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "depthnet":
             mid = H // 2
