@@ -9,71 +9,82 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 64, TN = 64, TK = 32;
-
 // C[i,j] (+)= sum_k A[i*sa0 + k*sa1] * B[j*sb0 + k*sb1]  (+ bias[j]),  i < M, j < N, k < K
-// 256 threads = 4 waves, each a 32x32 sub-tile of the 64x64 workgroup tile.
+//
+// The training GEMMs are small (1024 rays x 256 features x K <= 1020) and there are ~140 of them per step, so the
+// kernel is built for latency, not for tile reuse: one workgroup = one 32x32 output tile (256-320 workgroups per
+// GEMM fill the chip), its 4 waves split K four ways, operands go global -> registers directly in MFMA layout (lane
+// (r, h) feeds row r with the k values 8q + 4h + m, m = 0..3, of its slice: no LDS staging, no barrier in the K
+// loop, all loads of a slice in flight at once), and the four partial tiles are summed through LDS in a fixed
+// order (deterministic).  v_mfma_f32_32x32x2_f32: exact fp32 products.
+template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ void __launch_bounds__(256)
 gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const float* __restrict__ B,
                     int64_t sb0, int64_t sb1, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
                     int M, int N, int K, int accumulate) {
-  __shared__ float As[TM][TK + 1];
-  __shared__ float Bs[TN][TK + 1];
+  __shared__ float red[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
-  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int kq = (((K + 3) / 4) + 7) & ~7;            // K slice per wave, a multiple of 8
+  const int kbeg = wave * kq, kend = min(K, kbeg + kq);
+  const int i = i0 + r, j = j0 + r;
+  const bool iok = i < M, jok = j < N;
+  const float* ap = A + static_cast<int64_t>(iok ? i : 0) * sa0;
+  const float* bp = B + static_cast<int64_t>(jok ? j : 0) * sb0;
   f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += TK) {
-    // consecutive threads walk whichever index is contiguous in memory (k for x / W rows, the row index
-    // for the transposed operands of the grad-weight product), so global loads coalesce in every variant
-    for (int e = threadIdx.x; e < TM * TK; e += 256) {
-      {
-        const int r = (sa1 == 1) ? e / TK : e % TM, kk = (sa1 == 1) ? e % TK : e / TM;
-        const int i = i0 + r, k = k0 + kk;
-        As[r][kk] = (i < M && k < K) ? A[i * sa0 + k * sa1] : 0.f;
-      }
-      {
-        const int r = (sb1 == 1) ? e / TK : e % TN, kk = (sb1 == 1) ? e % TK : e / TN;
-        const int j = j0 + r, k = k0 + kk;
-        Bs[r][kk] = (j < N && k < K) ? B[j * sb0 + k * sb1] : 0.f;
-      }
-    }
-    __syncthreads();
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  // 32 k per trip: 16 + 16 independent loads in flight, then 16 MFMAs
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    float a[16], b[16];
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 2) {
-      const float a = As[wr + (lane & 31)][kk + (lane >> 5)];
-      const float b = Bs[wc + (lane & 31)][kk + (lane >> 5)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int k = k0 + 8 * c + 4 * h + m;
+        const bool kok = k < kend;
+        a[4 * c + m] = (iok && kok) ? ap[A_KCONTIG ? k : k * sa1] : 0.f;
+        b[4 * c + m] = (jok && kok) ? bp[B_KCONTIG ? k : k * sb1] : 0.f;
+      }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
   }
-  const int j = j0 + wc + (lane & 31);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wr + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (i < M && j < N) {
-      float v = acc[r] + (bias ? bias[j] : 0.f);
-      float* c = C + i * ldc + j;
+  for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
+  __syncthreads();
+  // wave w finishes accumulator registers 4w .. 4w+3 (rows (q & 3) + 8 (q >> 2) + 4 h of the tile)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int q = 4 * wave + t;
+    const int row = i0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (row < M && jok) {
+      float v = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
+      if (bias) v += bias[j];
+      float* c = C + static_cast<int64_t>(row) * ldc + j;
       *c = accumulate ? *c + v : v;
     }
   }
 }
 
-// column sums: out[j] = sum_i X[i*ld + j]   (bias gradient).  Block = 64 columns x 4 row lanes; coalesced
-// 256-B row segments, LDS reduction over the row lanes.
-__global__ void __launch_bounds__(256)
+// column sums: out[j] = sum_i X[i*ld + j]   (bias gradient).  Block = 32 columns x 32 row lanes; coalesced
+// 128-B row segments, fixed-order LDS reduction over the row lanes.
+__global__ void __launch_bounds__(1024)
 colsum_kernel(const float* __restrict__ X, int64_t ld, int M, int N, float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
+  __shared__ float part[32][33];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
   float s = 0.f;
   if (j < N)
-    for (int i = rl; i < M; i += 4) s += X[i * ld + j];
+    for (int i = rl; i < M; i += 32) s += X[i * ld + j];
   part[rl][c] = s;
   __syncthreads();
-  if (rl == 0 && j < N) out[j] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+  if (rl == 0 && j < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += part[k][c];
+    out[j] = t;
+  }
 }
 
 // activation forward in place / backward: act 0 none, 1 relu, 2 leaky(0.01), 3 sigmoid
@@ -148,9 +159,15 @@ int ns_gemm_strided(const float* A_dev, int64_t sa0, int64_t sa1, const float* B
   NS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "bad shape");
   if (M == 0 || N == 0) return NS_OK;
   NS_REQUIRE(A_dev && B_dev && C_dev, "null pointer");
-  dim3 grid((N + TN - 1) / TN, (M + TM - 1) / TM);
-  gemm_strided_kernel<<<grid, 256, 0, ns::as_stream(stream)>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, C_dev, ldc,
-                                                              M, N, K, accumulate);
+  dim3 grid((N + 31) / 32, (M + 31) / 32);
+  hipStream_t s = ns::as_stream(stream);
+#define NS_GEMM(AK, BK) gemm_strided_kernel<AK, BK><<<grid, 256, 0, s>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, \
+                                                                        C_dev, ldc, M, N, K, accumulate)
+  if (sa1 == 1 && sb1 == 1) NS_GEMM(true, true);
+  else if (sa1 == 1) NS_GEMM(true, false);
+  else if (sb1 == 1) NS_GEMM(false, true);
+  else NS_GEMM(false, false);
+#undef NS_GEMM
   NS_LAUNCH_CHECK();
   return NS_OK;
 }
@@ -159,7 +176,7 @@ int ns_colsum(const float* X_dev, int64_t ld, int M, int N, float* out_dev, void
   NS_REQUIRE(M >= 0 && N >= 0, "bad shape");
   if (N == 0) return NS_OK;
   NS_REQUIRE(X_dev && out_dev, "null pointer");
-  colsum_kernel<<<(N + 63) / 64, 256, 0, ns::as_stream(stream)>>>(X_dev, ld, M, N, out_dev);
+  colsum_kernel<<<(N + 31) / 32, 1024, 0, ns::as_stream(stream)>>>(X_dev, ld, M, N, out_dev);
   NS_LAUNCH_CHECK();
   return NS_OK;
 }
