@@ -44,11 +44,15 @@ constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (rea
 #ifndef NS_FRAG_DEPTH
 #define NS_FRAG_DEPTH 2
 #endif
-constexpr int kFragDepth = NS_FRAG_DEPTH;
+constexpr int kFragDepth = NS_FRAG_DEPTH;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
 #ifndef NS_OB_GROUP
 #define NS_OB_GROUP 1
 #endif
-constexpr int kObGroup = NS_OB_GROUP;       // output blocks in flight in the output-block-major layers (layer_ob)   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
+constexpr int kObGroup = NS_OB_GROUP;       // output blocks in flight in the output-block-major layers (layer_ob)
+#ifndef NS_USE_16X16
+#define NS_USE_16X16 1
+#endif
+constexpr bool kUse16x16 = NS_USE_16X16 != 0;   // 16-bit NeRF kernel: 16x16x32 engine (1) or 32x32x16 output-block-major (0)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -167,6 +171,16 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 #define NS_LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
 #define NS_GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 
+// LDS-DMA of 16 (or 4) bytes per lane: LDS address = wave-uniform base (M0) + lane * size, global address per lane.
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gptr) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma4(const void* gptr, uint32_t lds_base) {
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gptr) : "memory", "m0");
+}
+
 // Ring of kRingDepth LDS slots + a kFragDepth-deep register pipeline of A fragments.
 //
 // Slab timeline (t = slab being multiplied):  slot t%4 is read by the MFMAs, slot (t+1)%4 has landed
@@ -179,12 +193,13 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 // MI355X_MICROARCH.md "Two waves per SIMD", item 9) LAG slabs behind the first half, so that one
 // partner's layer epilogue / tile prologue (VALU, global loads) runs under the other's MFMAs instead
 // of both leaving the matrix pipe idle at once.  It costs LAG more ring slots.
-template <class M, int NWAVES, int LAG = 0, int DEPTH = kFragDepth>
+template <class M, int NWAVES, int LAG = 0, int DEPTH = kFragDepth, int AHEAD = kRingBase - 1>
 struct Pipe {
+  static_assert(AHEAD >= 2, "the slab after the open one must have landed, one more must be in flight");
   static constexpr int kDepth = DEPTH;   // A fragments in flight (LDS read-ahead, in chunks)
   using AFrag = typename M::AFrag;
   static constexpr int LPW = kSlabChunks / NWAVES;  // DMA instructions per wave per slab
-  static constexpr int RING = kRingBase + LAG;
+  static constexpr int RING = AHEAD + 1 + LAG;   // slabs issued ahead of the open one, + the open one
   static constexpr int kLdsBytes = RING * kSlabBytes;
   const char* stream;   // device weight stream, n_slabs * 16 KiB, cyclic
   char* lds;            // ring base in LDS
@@ -198,27 +213,27 @@ struct Pipe {
   uint32_t nxt;         // ... and in the following one
   AFrag f[DEPTH];       // fragments of the next DEPTH chunks
 
+  // One slab: LPW LDS-DMA instructions per wave.  They are issued through inline asm on purpose: with the
+  // __builtin_amdgcn_global_load_lds form the compiler's waitcnt pass sees an LDS store it cannot disambiguate and
+  // puts an s_waitcnt vmcnt(0) in front of the next LDS read of EVERY slab step -- the wave then waits out the L2
+  // round trip of the slab it has just requested, three slabs early, and the ring prefetches nothing (measured:
+  // MFMA pipe busy 52-69 % with it).  The asm form leaves the ordering to the counted wait + barrier of begin_slab().
   __device__ __forceinline__ void issue() {
     // wave-uniform part of the address in SGPRs, per-lane part a constant 32-bit offset (lane * 16)
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
-    char* dst = lds + issue_slot * kSlabBytes + wave * kChunkBytes;
+    const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
 #pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-      __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src + i * NWAVES * kChunkBytes + lane_off),
-                                       NS_LDS_PTR(dst + i * NWAVES * kChunkBytes), 16, 0, 0);
-    }
+    for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
   }
 
-  // s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields at their maxima = "don't wait"); gfx9 encoding:
-  // vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14.  The builtin (not inline asm) keeps
-  // the compiler's own counter bookkeeping exact, so its LDS waits stay counted (lgkmcnt(N > 0)).
+  // s_waitcnt vmcnt(N) alone (the other counters at "don't wait")
   template <int N>
   __device__ static __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "unexpected DMA count");
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
   }
 
   // A-fragment read: a plain LDS load (ds_read_b128 from a lane-linear image, conflict-free).  Measured
@@ -233,8 +248,9 @@ struct Pipe {
   __device__ __forceinline__ void init(const char* stream_, char* lds_, uint32_t n_slabs_, int wave_, int lane_) {
     stream = stream_; lds = lds_; n_slabs = n_slabs_; wave = wave_; lane = lane_;
     issue_slab = 0; issue_slot = 0; read_slot = 0;
-    issue(); issue(); issue();                    // slabs 0, 1, 2
-    wait_vm<2 * LPW>();                           // my pieces of slab 0 have landed ...
+    lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
+    static_for<AHEAD>([&](auto) { issue(); });    // slabs 0 .. AHEAD-1
+    wait_vm<(AHEAD - 1) * LPW>();                 // my pieces of slab 0 have landed ...
     __builtin_amdgcn_s_barrier();                 // ... and everyone else's
     asm volatile("" ::: "memory");
     lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
@@ -251,7 +267,7 @@ struct Pipe {
 
   // take part in a slab step (wait, barrier, DMA issue) without opening a slab
   __device__ __forceinline__ void idle_slab() {
-    wait_vm<LPW>();
+    wait_vm<(AHEAD - 2) * LPW>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue();
@@ -271,7 +287,7 @@ struct Pipe {
   // Open the next slab: its first kFragDepth fragments are already in registers.
   __device__ __forceinline__ void begin_slab() {
 #ifndef NS_EXP_NOWAIT     // NS_EXP_*: timing ablations only (results are wrong)
-    wait_vm<LPW>();                               // my pieces of the slab AFTER this one have landed
+    wait_vm<(AHEAD - 2) * LPW>();                 // my pieces of the slab AFTER this one have landed
 #endif
 #ifndef NS_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
@@ -358,6 +374,9 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
 // pieces and barriers per MFMA, at one wave per SIMD).
 
 // op(P, frag) is called for chunk P = 0..TOTAL-1 of the stream, in order, with the chunk's A fragment.
+// op(P, frag, load_next) is called for chunk P = 0..TOTAL-1 of the stream, in order, with the chunk's A fragment;
+// it must call load_next() exactly once (it re-fills the fragment register with the chunk DEPTH ahead), at the point
+// of its instruction stream where the LDS read should issue.
 template <int TOTAL, class PipeT, class F>
 __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
   constexpr int SLABS = (TOTAL + kSlabChunks - 1) / kSlabChunks;
@@ -368,11 +387,13 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
     pipe.begin_slab();
     static_for<USED>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
-      op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth]);
-      if constexpr (p + PipeT::kDepth < USED)
-        pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
-      else
-        pipe.template load<(p + PipeT::kDepth - USED) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.nxt);
+      auto load_next = [&] {
+        if constexpr (p + PipeT::kDepth < USED)
+          pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
+        else
+          pipe.template load<(p + PipeT::kDepth - USED) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.nxt);
+      };
+      op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth], load_next);
     });
   });
 }
@@ -432,8 +453,10 @@ __device__ __forceinline__ void layer_ob(PipeT& pipe, const float* bias_lds, int
   static_for<G>([&](auto g_) {
     static_for<T>([&](auto t_) { c[0][decltype(g_)::value][decltype(t_)::value] = load_bias_block(bias_lds, decltype(g_)::value, h); });
   });
-  stream_chunks<(NBO / G) * STEPS>(pipe, [&](auto P_, const typename M::AFrag& frag) {
+  stream_chunks<(NBO / G) * STEPS>(pipe, [&](auto P_, const typename M::AFrag& frag_ref, auto&& load_next) {
     constexpr int P = decltype(P_)::value;
+    const typename M::AFrag frag = frag_ref;   // the register is re-filled below
+    load_next();
     constexpr int gb = P / STEPS, step = P % STEPS, kc = step / G, g = step % G, par = gb & 1;
     static_for<T>([&](auto t_) {
       M::template mma<kc % M::CPB>(c[par][g][decltype(t_)::value], frag, in(t_, std::integral_constant<int, kc / M::CPB>{}));
@@ -599,6 +622,204 @@ __host__ __device__ inline int embed6_col(int k) {
   if (t < 60) return 6 + 12 * (t / 6) + 6 * h + (t % 6);
   if (t < 63) return (h ? 3 : 0) + (t - 60);
   return -1;
+}
+
+
+// =================================================================================================
+// 16x16x32 engine (v_mfma_f32_16x16x32_{bf16,f16}).  Measured on MI355X (tools/mfma_peak.hip): under
+// the power cap a bare loop of this shape sustains 2.14 PFLOP/s with live operands, the 32x32x16
+// shape 1.87 -- the 4-register accumulator moves half the accumulator bytes per flop.  The fused-MLP
+// scheme carries over: a wave owns T tiles of 16 samples; lane (n, g) = (lane & 15, lane >> 4) holds,
+// for sample n, eight features of every 32-feature K-block; a 16-feature output sub-block finishes
+// as 4 fp32 registers per tile, and two consecutive sub-blocks pack into exactly the B operand of
+// K-block s of the next layer:
+//     element e of lane group g  <->  feature 32 s + 16 (e >> 2) + 4 g + (e & 3).
+// The host packer (ns_pack.hip, layout 16) orders weight rows/columns by the same map.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+#ifndef NS_OB16_DEPTH
+#define NS_OB16_DEPTH 4
+#endif
+#ifndef NS_OB16_INTERLEAVE
+#define NS_OB16_INTERLEAVE 0   // 1: fence the 16x16x32 chunk step into MFMA / other / MFMA / other (measured: -3 %, not used)
+#endif
+#ifndef NS_OB16_AHEAD
+#define NS_OB16_AHEAD 3
+#endif
+constexpr int kOb16Depth = NS_OB16_DEPTH;   // A-fragment read-ahead of the 16x16x32 kernels (one wave per SIMD)
+constexpr int kOb16Ahead = NS_OB16_AHEAD;   // weight slabs in flight ahead of the open one
+
+struct Mma16BF16 {
+  static constexpr int kDtype = 1;
+  using AFrag = bf16x8;
+  struct Block { bf16x8 v; };                       // one lane's 8 features of a 32-feature K-block
+  template <bool RELU>
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) { return MmaBF16::pack2<RELU>(a, b); }
+  __device__ static __forceinline__ void mma(f32x4a& acc, const AFrag& a, const Block& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.v, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ Block from_f32(const float (&x)[8]) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = {pack2<false>(x[0], x[1]), pack2<false>(x[2], x[3]), pack2<false>(x[4], x[5]), pack2<false>(x[6], x[7])};
+    Block b; b.v = __builtin_bit_cast(bf16x8, w); return b;
+  }
+};
+struct Mma16F16 {
+  static constexpr int kDtype = 2;
+  using AFrag = f16x8;
+  struct Block { f16x8 v; };
+  template <bool RELU>
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) { return MmaF16::pack2<RELU>(a, b); }
+  __device__ static __forceinline__ void mma(f32x4a& acc, const AFrag& a, const Block& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.v, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ Block from_f32(const float (&x)[8]) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = {pack2<false>(x[0], x[1]), pack2<false>(x[2], x[3]), pack2<false>(x[4], x[5]), pack2<false>(x[6], x[7])};
+    Block b; b.v = __builtin_bit_cast(f16x8, w); return b;
+  }
+};
+
+// feature index (within a layer input of 32-feature K-blocks) held by element e of lane group g of K-block s
+__host__ __device__ constexpr int feature16(int s, int g, int e) { return 32 * s + 16 * (e >> 2) + 4 * g + (e & 3); }
+
+// chunks a layer of NSB 16-row output sub-blocks x NKB K-blocks consumes, padded to the fragment pipeline depth
+__host__ __device__ constexpr int ob16_chunks(int nsb, int nkb, int depth) { return ((nsb * nkb + depth - 1) / depth) * depth; }
+__host__ __device__ constexpr int ob16_layer_slabs(int nsb, int nkb, int depth) {
+  return (ob16_chunks(nsb, nkb, depth) + kSlabChunks - 1) / kSlabChunks;
+}
+
+// dword J (0..1) of the finished sub-block SB of one tile goes to dword 2 (SB & 1) + J of K-block SB >> 1
+template <class M, bool RELU, int SB, int J>
+__device__ __forceinline__ void convert_piece16(typename M::Block& out, const f32x4a& c) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = __builtin_bit_cast(u32x4, out.v);
+  w[2 * (SB & 1) + J] = M::template pack2<RELU>(c[2 * J], c[2 * J + 1]);
+  out.v = __builtin_bit_cast(typename M::AFrag, w);
+}
+
+// One layer: out[t][sb >> 1] <- act(bias + W . in) for the NSB 16-feature output sub-blocks but the last, whose raw
+// accumulators are returned in last[t] (heads read them; hidden layers convert_last16() them).
+//   in(t_, kb_) -> Block of tile t, K-block kb (compile-time indices); bias_lds: this layer's biases, natural order.
+// Stream order: for each sub-block, its NKB chunks (then zero chunks up to a multiple of the pipeline depth).
+template <class M, int T, int NSB, int NKB, bool RELU, class PipeT, class OutT, class InF>
+__device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, int g, OutT& out, f32x4a (&last)[T], InF&& in) {
+  constexpr int REAL = NSB * NKB;
+  constexpr int TOTAL = ob16_chunks(NSB, NKB, PipeT::kDepth);
+  constexpr int PIECES = 2 * T;                       // conversion pieces of one finished sub-block
+  constexpr int PPS = (PIECES + NKB - 1) / NKB;       // pieces issued per chunk step of the following sub-block
+  constexpr int CONV_END = (PIECES + PPS - 1) / PPS;
+  constexpr int BIAS_AT = (NKB - 2) > CONV_END ? (NKB - 2) : (NKB - 1);
+  f32x4a c[2][T];
+  {
+    const f32x4a b0 = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);
+    static_for<T>([&](auto t_) { c[0][decltype(t_)::value] = b0; });
+  }
+  // A lone wave issues in order: an instruction placed after the MFMA cluster overlaps only the LAST MFMA's
+  // execution (16 cycles for this shape), one placed between two MFMAs hides in the wait for the matrix pipe.  So the
+  // step is emitted as MFMA / conversion piece / MFMA / fragment read / MFMA / bias / MFMA with scheduling fences.
+  stream_chunks<TOTAL>(pipe, [&](auto P_, const typename M::AFrag& frag_ref, auto&& load_next) {
+    constexpr int P = decltype(P_)::value;
+    if constexpr (P < REAL) {
+      constexpr int sb = P / NKB, kc = P % NKB, par = sb & 1;
+      const typename M::AFrag frag = frag_ref;
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        M::mma(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}));
+#if NS_OB16_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if constexpr (t == 0 && sb > 0) {
+          static_for<PPS>([&](auto i_) {
+            constexpr int piece = kc * PPS + decltype(i_)::value;
+            if constexpr (piece < PIECES)
+              convert_piece16<M, RELU, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
+          });
+        }
+        if constexpr (t == (T > 1 ? 1 : 0)) load_next();
+        if constexpr (t == (T > 2 ? 2 : T - 1) && kc == BIAS_AT && sb + 1 < NSB) {
+          const f32x4a bn = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
+          static_for<T>([&](auto u_) { c[par ^ 1][decltype(u_)::value] = bn; });
+        }
+      });
+    } else {
+      load_next();
+    }
+  });
+  static_for<T>([&](auto t_) { last[decltype(t_)::value] = c[(NSB - 1) & 1][decltype(t_)::value]; });
+}
+template <class M, bool RELU, int T, int NSB, class OutT>
+__device__ __forceinline__ void convert_last16(OutT& out, const f32x4a (&last)[T]) {
+  static_for<T>([&](auto t_) {
+    static_for<2>([&](auto j_) {
+      convert_piece16<M, RELU, NSB - 1, decltype(j_)::value>(out[decltype(t_)::value][(NSB - 1) >> 1], last[decltype(t_)::value]);
+    });
+  });
+}
+
+// 3-component, L-level embedding of one sample into NKB K-blocks for lane group g = 2u + c: the lane's element e
+// of K-block kb is slot q = 16 kb + 8 u + e; q < 3L: level q / 3, component q % 3, sine (c = 0) or cosine (c = 1);
+// q = 3L: raw x0 (c = 0) / x2 (c = 1); q = 3L + 1: raw x1 (c = 0) / pad; beyond: pad.
+template <class M, bool PRECISE, int L, int NKB>
+__device__ __forceinline__ void embed3_16(typename M::Block (&out)[NKB], const float (&p)[3], int g) {
+  const Trig<PRECISE> t0(p[0]), t1(p[1]), t2(p[2]);
+  const int u = g >> 1, c = g & 1;
+  static_for<NKB>([&](auto kb_) {
+    constexpr int kb = decltype(kb_)::value;
+    float x[8];
+    static_for<8>([&](auto e_) {
+      constexpr int e = decltype(e_)::value;
+      // slot for u = 0 and for u = 1 (u is a run-time lane property): evaluate the one this lane owns
+      constexpr int q0 = 16 * kb + e, q1 = q0 + 8;
+      auto slot = [&](auto q_) -> float {
+        constexpr int q = decltype(q_)::value;
+        if constexpr (q < 3 * L) {
+          constexpr int comp = q % 3;
+          return (comp == 0 ? t0 : (comp == 1 ? t1 : t2))(q / 3, c);
+        } else if constexpr (q == 3 * L) {
+          return c ? p[2] : p[0];
+        } else if constexpr (q == 3 * L + 1) {
+          return c ? 0.0f : p[1];
+        } else {
+          return 0.0f;
+        }
+      };
+      // both candidates share the instruction stream when they are the same kind of slot; select by u
+      if constexpr (q1 < 3 * L) {
+        constexpr int comp0 = q0 % 3, comp1 = q1 % 3;
+        const Trig<PRECISE>& ta = comp0 == 0 ? t0 : (comp0 == 1 ? t1 : t2);
+        const Trig<PRECISE>& tb = comp1 == 0 ? t0 : (comp1 == 1 ? t1 : t2);
+        x[e] = u ? tb(q1 / 3, c) : ta(q0 / 3, c);
+      } else {
+        x[e] = u ? slot(std::integral_constant<int, q1>{}) : slot(std::integral_constant<int, q0>{});
+      }
+    });
+    out[kb] = M::from_f32(x);
+  });
+}
+// reference column (run_nerf_helpers.py:44-45 order) of feature index k of an embed3_16 segment, or -1 for padding
+__host__ __device__ inline int embed3_col16(int k, int L) {
+  const int kb = k >> 5, r = k & 31;
+  const int e = (r & 3) + 4 * (r >> 4), g = (r >> 2) & 3;     // inverse of feature16()
+  const int u = g >> 1, c = g & 1;
+  const int q = 16 * kb + 8 * u + e;
+  if (q < 3 * L) return 3 + 6 * (q / 3) + 3 * c + (q % 3);
+  if (q == 3 * L) return c ? 2 : 0;
+  if (q == 3 * L + 1) return c ? -1 : 1;
+  return -1;
+}
+// pre-embedded input row (NeRF.forward on [M, 90]) into the same slots
+template <class M, int L, int NKB>
+__device__ __forceinline__ void gather3_16(typename M::Block (&out)[NKB], const float* row, int g) {
+  static_for<NKB>([&](auto kb_) {
+    constexpr int kb = decltype(kb_)::value;
+    float x[8];
+    static_for<8>([&](auto e_) {
+      constexpr int e = decltype(e_)::value;
+      const int col = embed3_col16(feature16(kb, g, e), L);
+      x[e] = col >= 0 ? row[col] : 0.0f;
+    });
+    out[kb] = M::from_f32(x);
+  });
 }
 
 }  // namespace nsmlp

@@ -178,6 +178,10 @@ int ns_nerf_forward_ob(const ns_weights* net, const float* pts_dev, const float*
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
                        float* raw_dev, hipStream_t stream);
 
+int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
+                         const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
+                         float* raw_dev, hipStream_t stream);
+
 extern "C" {
 
 int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_dev,
@@ -189,6 +193,9 @@ int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_
   NS_REQUIRE(raw_dev && viewdirs_dev, "null pointer");
   NS_REQUIRE(pts_dev || (o_dev && d_dev && z_dev), "need pts or (o, d, z)");
   NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  if (net->layout == 16)
+    return ns_nerf_forward_ob16(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
+                                ns::as_stream(stream));
   if (net->layout > 0)
     return ns_nerf_forward_ob(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
                               ns::as_stream(stream));
@@ -208,6 +215,9 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
   if (M == 0) return NS_OK;
   NS_REQUIRE(x_dev && raw_dev, "null pointer");
   NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  if (net->layout == 16)
+    return ns_nerf_forward_ob16(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
+                                ns::as_stream(stream));
   if (net->layout > 0)
     return ns_nerf_forward_ob(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
                               ns::as_stream(stream));

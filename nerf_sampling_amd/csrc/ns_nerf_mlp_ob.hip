@@ -89,8 +89,7 @@ nerf_mlp_ob_kernel(NerfObArgs a) {
         const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
                                               : sidx / a.N;
         auto put = [&](int slot, const float* src) {
-          __builtin_amdgcn_global_load_lds(NS_GLB_PTR(src),
-                                           NS_LDS_PTR(static_cast<uintptr_t>(stage_base + (t * 10 + slot) * 256)), 4, 0, 0);
+          lds_dma4(src, stage_base + (t * 10 + slot) * 256);
         };
         if (a.pts) {
 #pragma unroll

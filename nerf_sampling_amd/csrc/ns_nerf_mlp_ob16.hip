@@ -1,0 +1,258 @@
+// Radiance-field MLP forward for the 16-bit operand paths (bf16 / f16) on v_mfma_f32_16x16x32: the shape that
+// sustains the most under the MI355X power cap (tools/mfma_peak.hip: 2.14 vs 1.87 PFLOP/s for 32x32x16 with live
+// operands).  Same operator as ns_nerf_mlp.hip (run_network + NeRF.forward, Trainer.py:789-806 and
+// run_nerf_helpers.py:67-134): positional encoding of points and view directions, DxW trunk with the input skip,
+// sigma head, feature/view/rgb head, one persistent kernel.  A wave owns T = 4 tiles of 16 samples (64 samples);
+// every A fragment (16 output rows x 32 input features, 1 KiB) read from LDS feeds 4 MFMAs; layers are walked one
+// 16-row output sub-block at a time (layer_ob16 in ns_mlp_engine.h; weight stream layout 16 of ns_pack.hip).
+#include "ns_common.h"
+#include "ns_mlp_engine.h"
+#include "ns_weights.h"
+
+namespace {
+
+using namespace nsmlp;
+
+constexpr int kT = 4;        // 16-sample tiles per wave
+constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + accumulators per wave
+
+struct Nerf16Args {
+  const char* stream;
+  const float* bias;
+  uint32_t n_slabs;
+  int bias_floats;
+  int D, skip;
+  // inputs: either pts [S,3] or (o,d [R,3], z [S]); or x [S,90] pre-embedded
+  const float* pts;
+  const float* o;
+  const float* d;
+  const float* z;
+  const float* viewdirs;
+  const float* x90;
+  int64_t S;
+  int N;
+  float* raw;
+};
+
+template <class M, int NKB, bool EMBEDDED>   // NKB = W / 32 K-blocks of a hidden layer
+__global__ void __launch_bounds__(kWaves * 64)
+nerf_mlp_ob16_kernel(Nerf16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = kT, NWAVES = kWaves, NSB = 2 * NKB;   // 16-row output sub-blocks of a hidden layer
+  using Block = typename M::Block;
+  using PipeT = Pipe<M, NWAVES, 0, kOb16Depth, kOb16Ahead>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+
+  // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 10 x 256 B]
+  float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
+  for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
+  __syncthreads();
+
+  typedef typename M::AFrag __attribute__((address_space(3))) * StashPtr;
+  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(smem)));
+  const uint32_t stash_region = lds0 + PipeT::kLdsBytes + ((static_cast<uint32_t>(a.bias_floats) * 4u + 15u) & ~15u);
+  const uint32_t stash_base = stash_region + static_cast<uint32_t>(wave) * (T * 3 * 1024) + static_cast<uint32_t>(lane) * 16u;
+  auto stash_at = [&](int t, int b) -> StashPtr {
+    return reinterpret_cast<StashPtr>(static_cast<uintptr_t>(stash_base + (t * 3 + b) * 1024));
+  };
+  auto stash_put = [&](int t, int b, const Block& v) { *stash_at(t, b) = v.v; };
+  auto stash_get = [&](int t, int b) -> Block { Block v; v.v = *stash_at(t, b); return v; };
+  // staging: value slot k (0..9) of sample j (0..63) of this wave's group at stage_base + k * 256 + j * 4
+  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (10 * 256);
+
+  PipeT ring;
+  ring.init(a.stream, smem, a.n_slabs, wave, lane);
+
+  const int64_t n_tiles = (a.S + 15) / 16;
+  const int64_t n_groups = (n_tiles + NWAVES * T - 1) / (NWAVES * T);
+  // sample held by lane `l16` (0..15) of tile t of this wave in group grp; clamped to a real sample
+  auto sample_of = [&](int64_t grp, int t, int l16, bool& valid) -> int64_t {
+    const int64_t sidx = ((grp * NWAVES + wave) * T + t) * 16 + l16;
+    valid = sidx < a.S;
+    return valid ? sidx : a.S - 1;
+  };
+  // Inputs of the NEXT group are fetched right after layer 0 of the current one by LDS-DMA (no registers held across
+  // the network): lane j of the wave fetches the ten values of the j-th of the wave's 64 consecutive samples.
+  // pts mode: p 0..2, v 7..9;  (o, d, z) mode: o 0..2, d 3..5, z 6, v 7..9.
+  auto prefetch = [&](int64_t grp) {
+    if constexpr (!EMBEDDED) {
+      bool valid;
+      const int64_t sidx = sample_of(grp, lane >> 4, lane & 15, valid);
+      const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
+                                            : sidx / a.N;
+      auto put = [&](int slot, const float* src) {
+        lds_dma4(src, stage_base + slot * 256);
+      };
+      if (a.pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(c, a.pts + sidx * 3 + c);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
+        put(6, a.z + sidx);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+    }
+  };
+  auto staged = [&](int t, int slot) -> float {
+    return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
+        static_cast<uintptr_t>(stage_base + slot * 256 + (t * 16 + n) * 4));
+  };
+
+  prefetch(blockIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    Block xe[T][2];   // embedded point (63 -> 64 features); registers for layer 0 only
+    asm volatile("" ::: "memory");   // the staged inputs landed several slab steps ago (in-order vmcnt)
+    static_for<T>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      Block ve[1];    // embedded view direction (27 -> 32)
+      if constexpr (EMBEDDED) {
+        bool valid;
+        const float* row = a.x90 + sample_of(grp, t, n, valid) * 90;
+        gather3_16<M, 10, 2>(xe[t], row, g);
+        gather3_16<M, 4, 1>(ve, row + 63, g);
+      } else {
+        float p[3], v[3];
+        if (a.pts) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) p[c] = staged(t, c);
+        } else {
+          const float zz = staged(t, 6);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) p[c] = staged(t, c) + staged(t, 3 + c) * zz;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
+        embed3_16<M, false, 10, 2>(xe[t], p, g);
+        embed3_16<M, false, 4, 1>(ve, v, g);
+      }
+      stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, ve[0]);
+    });
+
+    const float* bias = bias_lds;
+    Block hA[T][NKB], hB[T][NKB];
+    f32x4a last[T];
+    auto in_x = [&](auto t_, auto kb_) -> const Block& { return xe[decltype(t_)::value][decltype(kb_)::value]; };
+    auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
+    auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
+    auto in_xA = [&](auto t_, auto kb_) -> Block {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hA[decltype(t_)::value][kb - 2];
+    };
+    auto in_xB = [&](auto t_, auto kb_) -> Block {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hB[decltype(t_)::value][kb - 2];
+    };
+
+    // layer 0: x -> hA
+    layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
+    // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
+    // have been consumed (they fed the embeddings above)
+    prefetch(grp + gridDim.x);
+    int l = 1;
+    // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
+    for (; l + 1 < a.D; l += 2) {
+      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
+      convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
+      if (l == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB);
+      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
+      convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
+    }
+    if (l < a.D) {  // odd layer left over: hA -> hB, then move back
+      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
+      convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
+      static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
+    }
+    // sigma head (W -> 1): row 0 of a 16-row sub-block (lane group 0, register 0)
+    float sigma[T];
+    layer_ob16<M, T, 1, NKB, false>(ring, bias, g, hB, last, in_A); bias += 16;
+    static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
+    // feature (W -> W, no activation): hA -> hB
+    layer_ob16<M, T, NSB, NKB, false>(ring, bias, g, hB, last, in_A); bias += NSB * 16;
+    convert_last16<M, false, T, NSB>(hB, last);
+    // views: cat[feature, dirs27] -> W/2, relu: (hB, ve) -> hA[0 .. NKB/2)
+    auto in_Bv = [&](auto t_, auto kb_) -> Block {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
+    };
+    layer_ob16<M, T, NSB / 2, NKB + 1, true>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2) * 16;
+    convert_last16<M, true, T, NSB / 2>(hA, last);
+    // rgb (W/2 -> 3): rows 0..2 (lane group 0, registers 0..2)
+    layer_ob16<M, T, 1, NKB / 2, false>(ring, bias, g, hB, last, in_A);
+
+    if (g == 0) {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        bool valid;
+        const int64_t sidx = sample_of(grp, t, n, valid);
+        if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = make_float4(last[t][0], last[t][1], last[t][2], sigma[t]);
+      });
+    }
+  }
+  ring.finish();
+}
+
+int ob16_program_slabs(int W, int D, int skip) {
+  const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
+  int n = ob16_layer_slabs(NSB, 2, dp);
+  for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, (l - 1 == skip) ? NKB + 2 : NKB, dp);
+  n += ob16_layer_slabs(1, NKB, dp) + ob16_layer_slabs(NSB, NKB, dp) + ob16_layer_slabs(NSB / 2, NKB + 1, dp) +
+       ob16_layer_slabs(1, NKB / 2, dp);
+  return n;
+}
+
+template <class M, int NKB, bool EMB>
+int launch(Nerf16Args& a, hipStream_t stream) {
+  const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
+                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
+                     static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash | input staging
+  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(lds)));
+    attr_set = true;
+  }
+  const int64_t n_tiles = (a.S + 15) / 16;
+  const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
+  int cus = ns::cu_count();
+  if (cus <= 0) cus = 256;
+  const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
+  kern<<<grid, kWaves * 64, lds, stream>>>(a);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+template <class M, bool EMB>
+int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
+  return net->width == 256 ? launch<M, 8, EMB>(a, stream) : launch<M, 4, EMB>(a, stream);
+}
+
+}  // namespace
+
+// called by ns_nerf_forward / ns_nerf_forward_embedded for handles packed with layout 16 (arguments validated there)
+int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
+                         const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
+                         float* raw_dev, hipStream_t stream) {
+  if (ob16_program_slabs(net->width, net->depth, net->skip) != static_cast<int>(net->n_slabs)) {
+    ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
+                  ob16_program_slabs(net->width, net->depth, net->skip));
+    return NS_E_INVALID;
+  }
+  Nerf16Args a{};
+  a.stream = static_cast<const char*>(net->stream_dev);
+  a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
+  a.D = net->depth; a.skip = net->skip;
+  a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
+  a.S = S; a.N = N; a.raw = raw_dev;
+  const bool emb = x90_dev != nullptr;
+  if (net->dtype == NS_DTYPE_BF16) return emb ? dispatch_m<Mma16BF16, true>(net, a, stream) : dispatch_m<Mma16BF16, false>(net, a, stream);
+  if (net->dtype == NS_DTYPE_F16) return emb ? dispatch_m<Mma16F16, true>(net, a, stream) : dispatch_m<Mma16F16, false>(net, a, stream);
+  return NS_E_UNSUPPORTED;
+}

@@ -109,6 +109,42 @@ struct Builder {
     bytes.resize(base + slabs * kSlabBytes, 0);
   }
 
+  // Layout 16 (16x16x32 engine, layer_ob16<>()): chunk = 16 output rows x 32 input features; lane (n, g) holds
+  // row 16 sb + n and the features feature16(kb, g, e), e = 0..7, of K-block kb.
+  void fill_chunk16(uint8_t* chunk, const float* Wm, int out_f, int in_f, int sb, int kb,
+                    const std::function<int(int)>& colmap) const {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int n = 16 * sb + (lane & 15), g = lane >> 4;
+      for (int e = 0; e < 8; ++e) {
+        const int col = colmap(nsmlp::feature16(kb, g, e));
+        float v = 0.0f;
+        if (n < out_f && col >= 0) {
+          if (col >= in_f) { std::fprintf(stderr, "ns_pack: column %d out of range %d\n", col, in_f); std::abort(); }
+          v = Wm[static_cast<size_t>(n) * in_f + col];
+        }
+        put(chunk + lane * 16, e, v);
+      }
+    }
+  }
+  void layer_ob16(const float* Wm, int out_f, int in_f, int nsb, const std::vector<Seg>& segs) {
+    const size_t base = bytes.size();
+    size_t n = 0;
+    for (int sb = 0; sb < nsb; ++sb)
+      for (const Seg& sg : segs)
+        for (int kb = 0; kb < sg.nblk; ++kb) {
+          bytes.resize(base + (n + 1) * kChunkBytes, 0);
+          fill_chunk16(bytes.data() + base + n * kChunkBytes, Wm, out_f, in_f, sb, kb, sg.colmap);
+          ++n;
+        }
+    // zero chunks up to the fragment pipeline depth (the kernel walks them without MFMAs), then to a slab boundary
+    const size_t padded = (n + nsmlp::kOb16Depth - 1) / nsmlp::kOb16Depth * nsmlp::kOb16Depth;
+    const size_t slabs = (padded + kSlabChunks - 1) / kSlabChunks;
+    bytes.resize(base + slabs * kSlabBytes, 0);
+  }
+  void add_bias16(const float* b, int out_f, int nsb) {   // natural order, 16 per sub-block
+    for (int i = 0; i < 16 * nsb; ++i) bias.push_back(i < out_f ? b[i] : 0.0f);
+  }
+
   void add_bias(const float* b, int out_f, int nbo) {
     for (int nb = 0; nb < nbo; ++nb)
       for (int h = 0; h < 2; ++h)
@@ -152,8 +188,9 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   Builder bl(dtype);
   auto ident = [](int k) { return k; };
   auto xcol = [](int k) { return nsmlp::embed3_col(k, 10); };
-  const int layout = dtype == NS_DTYPE_F32 ? 0 : nsmlp::kObGroup;   // 0 = k-major; G > 0 = output-block-major, G in flight
-  bl.ob_group = layout > 0 ? layout : 1;
+  // 0 = k-major (fp32); 16 = 16x16x32 engine (bf16 / f16); G in 1..2 = 32x32x16 output-block-major, G blocks in flight
+  const int layout = dtype == NS_DTYPE_F32 ? 0 : (nsmlp::kUse16x16 ? 16 : nsmlp::kObGroup);
+  bl.ob_group = (layout > 0 && layout < 16) ? layout : 1;
   if (layout == 0) {
     // layer 0: 63 -> W
     bl.add_bias(b[0], W, NB);
@@ -179,6 +216,30 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     bl.segment(wf[2], W / 2, W + 27, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
     bl.add_bias(bf[3], 3, 1);
     bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
+  } else if (layout == 16) {
+    // same layers for the 16x16x32 kernel (ns_nerf_mlp_ob16.hip): NSB = out/16 sub-blocks, K-blocks of 32 features;
+    // hidden features arrive in feature16() order, i.e. plain feature indices for the column maps
+    auto xcol16 = [](int k) { return nsmlp::embed3_col16(k, 10); };
+    auto hcol = [](int k) { return 63 + k; };
+    const int NSB = W / 16, NKB = W / 32;
+    bl.add_bias16(b[0], W, NSB);
+    bl.layer_ob16(w[0], W, 63, NSB, {{2, xcol16}});
+    for (int l = 1; l < D; ++l) {
+      bl.add_bias16(b[l], W, NSB);
+      if (l - 1 == skip) bl.layer_ob16(w[l], W, W + 63, NSB, {{2, xcol16}, {NKB, hcol}});
+      else bl.layer_ob16(w[l], W, W, NSB, {{NKB, ident}});
+    }
+    const float* const* wf = w + D;
+    const float* const* bf = b + D;
+    bl.add_bias16(bf[1], 1, 1);
+    bl.layer_ob16(wf[1], 1, W, 1, {{NKB, ident}});
+    bl.add_bias16(bf[0], W, NSB);
+    bl.layer_ob16(wf[0], W, W, NSB, {{NKB, ident}});
+    bl.add_bias16(bf[2], W / 2, NSB / 2);
+    bl.layer_ob16(wf[2], W / 2, W + 27, NSB / 2,
+                  {{NKB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col16(k, 4); return c < 0 ? -1 : W + c; }}});
+    bl.add_bias16(bf[3], 3, 1);
+    bl.layer_ob16(wf[3], 3, W / 2, 1, {{NKB / 2, ident}});
   } else {
     // same layers, output-block-major (ns_nerf_mlp_ob.hip consumes them in this order)
     auto hcol = [](int k) { return 63 + k; };

@@ -41,6 +41,25 @@ __global__ void __launch_bounds__(512) rotating(const bf16x8* __restrict__ in, f
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Same rotating-operand loop on the other dense bf16 shape, v_mfma_f32_16x16x32_bf16 (4-register accumulators)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ void __launch_bounds__(512) rotating16(const bf16x8* __restrict__ in, float* out, int iters) {
+  bf16x8 a[8], b[8];
+  for (int i = 0; i < 8; ++i) { a[i] = in[(2 * i) * 512 + threadIdx.x]; b[i] = in[(2 * i + 1) * 512 + threadIdx.x]; }
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 7], b[(k + 3 * i) & 7], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int j = 0; j < 4; ++j) s += acc[i][j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main() {
   std::vector<uint16_t> h(16 * 512 * 8);
   srand(1);
@@ -77,6 +96,17 @@ int main() {
         double flop = (double)grid * (threads / 64) * iters * 8 * nacc * 2.0 * 32 * 32 * 16;
         printf("rotating operands%s, waves/SIMD %d: %.1f ms, %.1f TFLOP/s (%.1f%% of 2500)\n", relu ? " (B = relu)" : "", threads / 256, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0);
       }
+    }
+  }
+  for (int threads : {256, 512}) {
+    const int iters = 62500, nacc = 8, grid = 256;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      rotating16<8><<<grid, threads>>>(din, dout, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      double flop = (double)grid * (threads / 64) * iters * 8 * nacc * 2.0 * 16 * 16 * 32;
+      printf("16x16x32 rotating operands (B = relu), waves/SIMD %d: %.1f ms, %.1f TFLOP/s (%.1f%% of 2500)\n", threads / 256, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0);
     }
   }
   return 0;
