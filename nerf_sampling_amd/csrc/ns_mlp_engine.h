@@ -174,11 +174,11 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 // LDS-DMA of 16 (or 4) bytes per lane: LDS address = wave-uniform base (M0) + lane * size, global address per lane.
 __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
   const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gptr) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gptr) : "memory");   // (M0 is compiler-reserved; nothing else in these kernels uses it)
 }
 __device__ __forceinline__ void lds_dma4(const void* gptr, uint32_t lds_base) {
   const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gptr) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gptr) : "memory");   // (M0 is compiler-reserved; nothing else in these kernels uses it)
 }
 
 // Ring of kRingDepth LDS slots + a kFragDepth-deep register pipeline of A fragments.
@@ -760,37 +760,44 @@ __device__ __forceinline__ void convert_last16(OutT& out, const f32x4a (&last)[T
 // of K-block kb is slot q = 16 kb + 8 u + e; q < 3L: level q / 3, component q % 3, sine (c = 0) or cosine (c = 1);
 // q = 3L: raw x0 (c = 0) / x2 (c = 1); q = 3L + 1: raw x1 (c = 0) / pad; beyond: pad.
 template <class M, bool PRECISE, int L, int NKB>
-__device__ __forceinline__ void embed3_16(typename M::Block (&out)[NKB], const float (&p)[3], int g) {
-  const Trig<PRECISE> t0(p[0]), t1(p[1]), t2(p[2]);
-  const int u = g >> 1, c = g & 1;
+__device__ __forceinline__ void embed3_16(typename M::Block (&out)[NKB], float p0, float p1, float p2, int g) {
+  // everything below selects VALUES, never objects: a `u ? a[i] : b[j]` on arrays or structs makes the compiler select
+  // the address instead and park the operands in scratch, whose reload waits on vmcnt, i.e. on the weight DMA
+  const Rev r0 = to_rev(p0), r1 = to_rev(p1), r2 = to_rev(p2);
+  const bool u = (g >> 1) != 0;
+  const int c = g & 1;
+  auto trig = [&](float hi, float lo, int level) -> float {
+    Trig<PRECISE> t(0.0f);
+    t.r.hi = hi; t.r.lo = lo;
+    return t(level, c);
+  };
   static_for<NKB>([&](auto kb_) {
     constexpr int kb = decltype(kb_)::value;
     float x[8];
     static_for<8>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      // slot for u = 0 and for u = 1 (u is a run-time lane property): evaluate the one this lane owns
-      constexpr int q0 = 16 * kb + e, q1 = q0 + 8;
-      auto slot = [&](auto q_) -> float {
+      constexpr int q0 = 16 * kb + e, q1 = q0 + 8;       // the slot for u = 0 and for u = 1
+      auto value = [&](auto q_) -> float {               // non-trigonometric slots
         constexpr int q = decltype(q_)::value;
-        if constexpr (q < 3 * L) {
-          constexpr int comp = q % 3;
-          return (comp == 0 ? t0 : (comp == 1 ? t1 : t2))(q / 3, c);
-        } else if constexpr (q == 3 * L) {
-          return c ? p[2] : p[0];
-        } else if constexpr (q == 3 * L + 1) {
-          return c ? 0.0f : p[1];
-        } else {
-          return 0.0f;
-        }
+        if constexpr (q == 3 * L) return c ? p2 : p0;
+        else if constexpr (q == 3 * L + 1) return c ? 0.0f : p1;
+        else return 0.0f;
       };
-      // both candidates share the instruction stream when they are the same kind of slot; select by u
-      if constexpr (q1 < 3 * L) {
-        constexpr int comp0 = q0 % 3, comp1 = q1 % 3;
-        const Trig<PRECISE>& ta = comp0 == 0 ? t0 : (comp0 == 1 ? t1 : t2);
-        const Trig<PRECISE>& tb = comp1 == 0 ? t0 : (comp1 == 1 ? t1 : t2);
-        x[e] = u ? tb(q1 / 3, c) : ta(q0 / 3, c);
+      auto comp_hi = [&](auto q_) -> float { constexpr int k = decltype(q_)::value % 3; return k == 0 ? r0.hi : (k == 1 ? r1.hi : r2.hi); };
+      auto comp_lo = [&](auto q_) -> float { constexpr int k = decltype(q_)::value % 3; return k == 0 ? r0.lo : (k == 1 ? r1.lo : r2.lo); };
+      using Q0 = std::integral_constant<int, q0>;
+      using Q1 = std::integral_constant<int, q1>;
+      if constexpr (q1 < 3 * L) {                         // both candidates are sin/cos slots: one evaluation
+        const float hi = u ? comp_hi(Q1{}) : comp_hi(Q0{});
+        const float lo = u ? comp_lo(Q1{}) : comp_lo(Q0{});
+        x[e] = trig(hi, lo, u ? q1 / 3 : q0 / 3);       // (the level is a lane property too: one v_ldexp)
+      } else if constexpr (q0 < 3 * L) {
+        const float tv = trig(comp_hi(Q0{}), comp_lo(Q0{}), q0 / 3);
+        const float ov = value(Q1{});
+        x[e] = u ? ov : tv;
       } else {
-        x[e] = u ? slot(std::integral_constant<int, q1>{}) : slot(std::integral_constant<int, q0>{});
+        const float a = value(Q0{}), b = value(Q1{});
+        x[e] = u ? b : a;
       }
     });
     out[kb] = M::from_f32(x);

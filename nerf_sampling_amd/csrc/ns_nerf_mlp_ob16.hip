@@ -127,8 +127,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
-        embed3_16<M, false, 10, 2>(xe[t], p, g);
-        embed3_16<M, false, 4, 1>(ve, v, g);
+        embed3_16<M, false, 10, 2>(xe[t], p[0], p[1], p[2], g);
+        embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
       }
       stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, ve[0]);
     });
