@@ -7,6 +7,10 @@
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
 
+#ifndef NS_DN_WAVES
+#define NS_DN_WAVES 8   // waves per workgroup of the 16-bit W = 256 kernel (8: two per SIMD, prologue spills; 4: one per SIMD)
+#endif
+
 namespace {
 
 using namespace nsmlp;
@@ -217,9 +221,9 @@ int ns_depthnet_forward(const ns_weights* net, const float* o_dev, const float* 
     case NS_DTYPE_F32:
       return NB == 8 ? launch<MmaF32, 8, 4, true>(net, a, s) : launch<MmaF32, 4, 4, true>(net, a, s);
     case NS_DTYPE_BF16:
-      return NB == 8 ? launch<MmaBF16, 8, 8, false>(net, a, s) : launch<MmaBF16, 4, 8, false>(net, a, s);
+      return NB == 8 ? launch<MmaBF16, 8, NS_DN_WAVES, false>(net, a, s) : launch<MmaBF16, 4, 8, false>(net, a, s);
     case NS_DTYPE_F16:
-      return NB == 8 ? launch<MmaF16, 8, 8, false>(net, a, s) : launch<MmaF16, 4, 8, false>(net, a, s);
+      return NB == 8 ? launch<MmaF16, 8, NS_DN_WAVES, false>(net, a, s) : launch<MmaF16, 4, 8, false>(net, a, s);
   }
   return NS_E_UNSUPPORTED;
 }

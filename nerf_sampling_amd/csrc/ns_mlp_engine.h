@@ -45,14 +45,6 @@ constexpr int kRingBase = 4;     // LDS slots without stagger: open, landed (rea
 #define NS_FRAG_DEPTH 2
 #endif
 constexpr int kFragDepth = NS_FRAG_DEPTH;   // A fragments kept in flight per wave (LDS read-ahead, in chunks)
-#ifndef NS_OB_GROUP
-#define NS_OB_GROUP 1
-#endif
-constexpr int kObGroup = NS_OB_GROUP;       // output blocks in flight in the output-block-major layers (layer_ob)
-#ifndef NS_USE_16X16
-#define NS_USE_16X16 1
-#endif
-constexpr bool kUse16x16 = NS_USE_16X16 != 0;   // 16-bit NeRF kernel: 16x16x32 engine (1) or 32x32x16 output-block-major (0)
 
 // ---- compile-time loop with constant indices (keeps register arrays statically indexed) ----
 template <int... I, class F>
@@ -362,18 +354,15 @@ __device__ __forceinline__ void to_blocks(typename M::Block (&out)[NBO], const f
   });
 }
 
-// ---- output-block-major layers ("ob" stream layout) ---------------------------------------------
+// ---- output-block-major layers (16x16x32 engine below) ------------------------------------------
 // The k-major consume<>() above finishes all NBO output blocks of a layer at the same MFMA, so the
-// bias loads and f32 -> 16-bit conversions of a whole layer (about one VALU op per MFMA) come in one
-// burst -- and because every wave of the workgroup meets at the same slab barriers, the two waves of a
-// SIMD burst TOGETHER and the matrix pipe idles.  Here a layer is walked one 32-feature output block
-// at a time (all K chunks of block nb, then block nb+1; the stream is packed in that order by
-// ns_pack.hip layout 1): only one block's accumulators are live, and the conversion of block nb is
-// issued piecewise between the MFMAs of block nb+1, so the VALU work hides under the matrix pipe of
-// the SAME wave.  T sample tiles per wave share every A fragment (T = 2: half the LDS reads, DMA
-// pieces and barriers per MFMA, at one wave per SIMD).
+// bias loads and f32 -> 16-bit conversions of a whole layer come in one burst.  The 16-bit NeRF kernel
+// instead walks a layer one output sub-block at a time (all K chunks of sub-block sb, then sb+1; the
+// stream is packed in that order by ns_pack.hip layout 16): only one sub-block's accumulators are live,
+// so a wave can own several sample tiles that share every A fragment, and the conversion of sub-block sb
+// is issued piecewise between the MFMAs of sub-block sb+1.  (Round 1 also had a 32x32x16 version of this
+// engine, two 32-sample tiles per wave; the 16x16x32 one replaced it)
 
-// op(P, frag) is called for chunk P = 0..TOTAL-1 of the stream, in order, with the chunk's A fragment.
 // op(P, frag, load_next) is called for chunk P = 0..TOTAL-1 of the stream, in order, with the chunk's A fragment;
 // it must call load_next() exactly once (it re-fills the fragment register with the chunk DEPTH ahead), at the point
 // of its instruction stream where the LDS read should issue.
@@ -397,92 +386,6 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
     });
   });
 }
-__host__ __device__ constexpr int ob_layer_slabs(int cpb, int nbo, int nkb) {
-  return (nbo * nkb * cpb + kSlabChunks - 1) / kSlabChunks;
-}
-
-// dword j (features 2j, 2j+1 of the lane's 16) of a 16-bit block from its fp32 accumulator
-template <class M, bool RELU, int J>
-__device__ __forceinline__ void convert_piece(typename M::Block& out, const f32x16& c) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w = __builtin_bit_cast(u32x4, out.v[J / 4]);
-  w[J % 4] = M::template pack2<RELU>(c[2 * J], c[2 * J + 1]);
-  out.v[J / 4] = __builtin_bit_cast(typename M::AFrag, w);
-}
-// the G blocks layer_ob() left unconverted: out[t][NBO - G + g] = act(last[g][t])
-template <class M, bool RELU, int T, int G, int NBO, class OutT>
-__device__ __forceinline__ void convert_last(OutT& out, const f32x16 (&last)[G][T]) {
-  static_for<G>([&](auto g_) {
-    static_for<T>([&](auto t_) {
-      static_for<8>([&](auto j_) {
-        convert_piece<M, RELU, decltype(j_)::value>(out[decltype(t_)::value][NBO - G + decltype(g_)::value],
-                                                    last[decltype(g_)::value][decltype(t_)::value]);
-      });
-    });
-  });
-}
-
-__device__ __forceinline__ f32x16 load_bias_block(const float* bias_lds, int nb, int h) {
-  const f32x4* b = reinterpret_cast<const f32x4*>(bias_lds + nb * 32 + h * 16);
-  f32x16 r;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const f32x4 v = b[g];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[4 * g + e] = v[e];
-  }
-  return r;
-}
-
-// One layer, G output blocks in flight (G independent MFMA accumulation chains per tile):
-//   out[t][nb] = act(bias[nb] + sum_kb W[nb, kb] . in(t, kb))   for nb < NBO - G;
-// the LAST group of G blocks is left unconverted in last[g][t] (heads read it raw; hidden layers
-// convert_last() it).  in(t_, kb_) -> const Block& with compile-time tile / K-block indices.
-// Stream order (ns_pack.hip layer_ob): for each group of G blocks, for each K chunk, the G blocks' chunks.
-template <class M, int T, int G, int NBO, int NKB, bool RELU, class PipeT, class OutT, class InF>
-__device__ __forceinline__ void layer_ob(PipeT& pipe, const float* bias_lds, int h, OutT& out, f32x16 (&last)[G][T],
-                                         InF&& in) {
-  static_assert(NBO % G == 0, "output blocks must come in whole groups");
-  constexpr int CH = NKB * M::CPB;                 // K chunks per output block
-  constexpr int STEPS = G * CH;                    // stream chunks per group
-  constexpr int PIECES = 8 * T * G;                // conversion pieces of one finished group
-  constexpr int PPS = (PIECES + STEPS - 1) / STEPS;
-  constexpr int CONV_END = (PIECES + PPS - 1) / PPS;   // step of the next group by which the conversion is done
-  constexpr int BIAS_AT = (STEPS - 4 * G) > CONV_END ? (STEPS - 4 * G) : (STEPS - 1);  // next group's bias fetch
-  f32x16 c[2][G][T];                               // accumulators: group parity x block in group x tile
-  static_for<G>([&](auto g_) {
-    static_for<T>([&](auto t_) { c[0][decltype(g_)::value][decltype(t_)::value] = load_bias_block(bias_lds, decltype(g_)::value, h); });
-  });
-  stream_chunks<(NBO / G) * STEPS>(pipe, [&](auto P_, const typename M::AFrag& frag_ref, auto&& load_next) {
-    constexpr int P = decltype(P_)::value;
-    const typename M::AFrag frag = frag_ref;   // the register is re-filled below
-    load_next();
-    constexpr int gb = P / STEPS, step = P % STEPS, kc = step / G, g = step % G, par = gb & 1;
-    static_for<T>([&](auto t_) {
-      M::template mma<kc % M::CPB>(c[par][g][decltype(t_)::value], frag, in(t_, std::integral_constant<int, kc / M::CPB>{}));
-    });
-    if constexpr (gb > 0) {                        // conversion of the previous group under this group's MFMAs
-      static_for<PPS>([&](auto i_) {
-        constexpr int piece = step * PPS + decltype(i_)::value;
-        if constexpr (piece < PIECES) {
-          constexpr int j = piece / (T * G), t = piece % T, gg = (piece % (T * G)) / T;
-          convert_piece<M, RELU, j>(out[t][(gb - 1) * G + gg], c[par ^ 1][gg][t]);
-        }
-      });
-    }
-    if constexpr (step == BIAS_AT && (gb + 1) * G < NBO) {
-      static_for<G>([&](auto g_) {
-        static_for<T>([&](auto t_) {
-          c[par ^ 1][decltype(g_)::value][decltype(t_)::value] = load_bias_block(bias_lds, (gb + 1) * G + decltype(g_)::value, h);
-        });
-      });
-    }
-  });
-  static_for<G>([&](auto g_) {
-    static_for<T>([&](auto t_) { last[decltype(g_)::value][decltype(t_)::value] = c[(NBO / G - 1) & 1][decltype(g_)::value][decltype(t_)::value]; });
-  });
-}
-
 // ---- positional-encoding slots -------------------------------------------------------------------
 // Lane half h = 0 evaluates sines, h = 1 cosines of the same argument (cos x = sin(x + pi/2)),
 // so both halves run the same instruction stream.

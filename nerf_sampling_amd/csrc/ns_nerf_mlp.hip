@@ -166,17 +166,13 @@ int dispatch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
   switch (net->dtype) {
     case NS_DTYPE_F32:
       return NB == 8 ? launch<MmaF32, 8, 4, 0, true, EMB>(net, a, stream) : launch<MmaF32, 4, 4, 0, true, EMB>(net, a, stream);
-    default:   // 16-bit handles are packed output-block-major and run in ns_nerf_mlp_ob.hip
+    default:   // 16-bit handles are packed for, and run in, ns_nerf_mlp_ob16.hip
       break;
   }
   return NS_E_UNSUPPORTED;
 }
 
 }  // namespace
-
-int ns_nerf_forward_ob(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
-                       const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                       float* raw_dev, hipStream_t stream);
 
 int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                          const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
@@ -196,9 +192,6 @@ int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
                                 ns::as_stream(stream));
-  if (net->layout > 0)
-    return ns_nerf_forward_ob(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
-                              ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
@@ -218,9 +211,6 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
                                 ns::as_stream(stream));
-  if (net->layout > 0)
-    return ns_nerf_forward_ob(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
-                              ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;

@@ -89,25 +89,7 @@ struct Builder {
     }
   }
 
-  // Layout 1 (output-block-major, layer_ob<>()): a whole layer = for each output block, the chunks of all
-  // its K-segments in order; padded to a slab boundary.
-  struct Seg { int nblk; std::function<int(int)> colmap; };
-  int ob_group = 1;   // output blocks in flight (G of layer_ob<>)
-  void layer_ob(const float* Wm, int out_f, int in_f, int nbo, const std::vector<Seg>& segs) {
-    const size_t base = bytes.size();
-    const int G = nbo % ob_group == 0 ? ob_group : 1;
-    size_t n = 0;
-    for (int gb = 0; gb < nbo / G; ++gb)
-      for (const Seg& sg : segs)
-        for (int kc = 0; kc < sg.nblk * cpb; ++kc)
-          for (int g = 0; g < G; ++g) {
-            bytes.resize(base + (n + 1) * kChunkBytes, 0);
-            fill_chunk(bytes.data() + base + n * kChunkBytes, Wm, out_f, in_f, gb * G + g, kc / cpb, kc % cpb, sg.colmap);
-            ++n;
-          }
-    const size_t slabs = (n + kSlabChunks - 1) / kSlabChunks;
-    bytes.resize(base + slabs * kSlabBytes, 0);
-  }
+  struct Seg { int nblk; std::function<int(int)> colmap; };   // a K-segment: nblk 32-feature blocks, column map
 
   // Layout 16 (16x16x32 engine, layer_ob16<>()): chunk = 16 output rows x 32 input features; lane (n, g) holds
   // row 16 sb + n and the features feature16(kb, g, e), e = 0..7, of K-block kb.
@@ -188,9 +170,7 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   Builder bl(dtype);
   auto ident = [](int k) { return k; };
   auto xcol = [](int k) { return nsmlp::embed3_col(k, 10); };
-  // 0 = k-major (fp32); 16 = 16x16x32 engine (bf16 / f16); G in 1..2 = 32x32x16 output-block-major, G blocks in flight
-  const int layout = dtype == NS_DTYPE_F32 ? 0 : (nsmlp::kUse16x16 ? 16 : nsmlp::kObGroup);
-  bl.ob_group = (layout > 0 && layout < 16) ? layout : 1;
+  const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;   // 0 = k-major (fp32 kernel); 16 = 16x16x32 engine (bf16 / f16)
   if (layout == 0) {
     // layer 0: 63 -> W
     bl.add_bias(b[0], W, NB);
@@ -240,27 +220,6 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
                   {{NKB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col16(k, 4); return c < 0 ? -1 : W + c; }}});
     bl.add_bias16(bf[3], 3, 1);
     bl.layer_ob16(wf[3], 3, W / 2, 1, {{NKB / 2, ident}});
-  } else {
-    // same layers, output-block-major (ns_nerf_mlp_ob.hip consumes them in this order)
-    auto hcol = [](int k) { return 63 + k; };
-    bl.add_bias(b[0], W, NB);
-    bl.layer_ob(w[0], W, 63, NB, {{2, xcol}});
-    for (int l = 1; l < D; ++l) {
-      bl.add_bias(b[l], W, NB);
-      if (l - 1 == skip) bl.layer_ob(w[l], W, W + 63, NB, {{2, xcol}, {NB, hcol}});
-      else bl.layer_ob(w[l], W, W, NB, {{NB, ident}});
-    }
-    const float* const* wf = w + D;
-    const float* const* bf = b + D;
-    bl.add_bias(bf[1], 1, 1);
-    bl.layer_ob(wf[1], 1, W, 1, {{NB, ident}});
-    bl.add_bias(bf[0], W, NB);
-    bl.layer_ob(wf[0], W, W, NB, {{NB, ident}});
-    bl.add_bias(bf[2], W / 2, NB / 2);
-    bl.layer_ob(wf[2], W / 2, W + 27, NB / 2,
-                {{NB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; }}});
-    bl.add_bias(bf[3], 3, 1);
-    bl.layer_ob(wf[3], 3, W / 2, 1, {{NB / 2, ident}});
   }
 
   ns_weights* h = new ns_weights();

@@ -9,7 +9,7 @@ struct ns_weights {
   int width;      // hidden width W (128 or 256)
   int depth;      // NeRF: D;  DepthNet: n_layers
   int skip;       // NeRF: skip index or -1
-  int layout;     // weight stream order: 0 = k-major slabs (consume<>), G > 0 = output-block-major, G blocks in flight (layer_ob<>)
+  int layout;     // weight stream order: 0 = k-major slabs (consume<>), 16 = 16x16x32 output-sub-block-major (layer_ob16<>)
   void* stream_dev;      // weight stream, n_slabs * 16 KiB, consumed cyclically by every workgroup
   uint32_t n_slabs;
   float* bias_dev;       // all biases in LDS image order, fp32
