@@ -32,7 +32,7 @@ DEPTHNET_FLOP_PER_RAY = 2 * 3_330_304
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # dense MFMA, MI355X_MICROARCH.md
 
 
-MEASURED_MFMA_CEILING = {"bf16": 1800.0, "f16": None, "f32": 155.0}   # TFLOP/s, see DESIGN.md section 6
+MEASURED_MFMA_CEILING = {"bf16": 2140.0, "f16": None, "f32": 155.0}   # TFLOP/s (bf16: bare 16x16x32 loop), DESIGN.md section 6
 
 
 def build_modules(scene_name, device):
@@ -187,7 +187,7 @@ def main():
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (not live);
     # only quoted for the exact workload they were collected on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01c_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r01e_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
@@ -218,10 +218,10 @@ def main():
                                    + f", seeded synthetic weights ({args.scene}), spiral render poses of load_blender.py",
                        "rays_per_step": H * W, "samples_per_ray": args.samples,
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
-            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_ob_kernel" if args.dtype != "f32" else "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_ob16_kernel" if args.dtype != "f32" else "nerf_mlp_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "kernel_ms": mlp_ms, "algorithmic_flop_per_launch": mlp_flop,
-                         # context, not the contract's peak: what a bare v_mfma_f32_32x32x16 loop whose A and B operands
+                         # context, not the contract's peak: what a bare v_mfma_f32_16x16x32 loop whose A and B operands
                          # change on every MFMA sustains on this part under its power cap (tools/mfma_peak.hip)
                          "measured_mfma_ceiling": MEASURED_MFMA_CEILING.get(args.dtype)},
         }
