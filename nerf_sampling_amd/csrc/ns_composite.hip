@@ -27,6 +27,49 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
   const int64_t ray_stride = (int64_t)gridDim.x * RAYS_PER_BLOCK;
   // all lanes of a wave iterate the same number of times (shuffles need full participation)
   const int64_t iters = (R + ray_stride - 1) / ray_stride;
+  if (N <= SW) {
+    // one chunk per ray: software-pipelined, the next ray's loads are in flight while this one is composited
+    struct In { int64_t r; bool ok, live; float4 q; float zi, dist_raw, nz, norm; };
+    auto fetch = [&](int64_t it) -> In {
+      In x;
+      x.r = it * ray_stride + (int64_t)blockIdx.x * RAYS_PER_BLOCK + threadIdx.x / SW;
+      x.live = it < iters && x.r < R;
+      x.ok = x.live && sub < N;
+      x.q = make_float4(0.f, 0.f, 0.f, 0.f);
+      x.zi = x.dist_raw = x.nz = x.norm = 0.f;
+      if (x.live) x.norm = nscomp::ray_norm(rays_d[x.r * 3], rays_d[x.r * 3 + 1], rays_d[x.r * 3 + 2]);
+      if (x.ok) {
+        const int64_t e = x.r * N + sub;
+        x.q = raw[e];
+        x.zi = z[e];
+        x.dist_raw = (sub < N - 1) ? z[e + 1] - x.zi : 1e10f;
+        if (noise) x.nz = noise[e];
+      }
+      return x;
+    };
+    In cur = fetch(0);
+    for (int64_t it = 0; it < iters; ++it) {
+      const In nxt = fetch(it + 1);
+      nscomp::RayAccum A;
+      float alpha, w, disp;
+      nscomp::composite_chunk<SW>(A, cur.ok, sub, cur.q, cur.zi, cur.dist_raw, cur.norm, cur.nz, noise != nullptr, alpha, w);
+      if (cur.ok) {
+        const int64_t e = cur.r * N + sub;
+        if (alphas_out) alphas_out[e] = alpha;
+        if (weights_out) weights_out[e] = w;
+      }
+      nscomp::composite_finish<SW>(A, white_bkgd, disp);
+      if (cur.live && sub == 0) {
+        const int64_t r = cur.r;
+        if (rgb_out) { rgb_out[r * 3] = A.r; rgb_out[r * 3 + 1] = A.g; rgb_out[r * 3 + 2] = A.b; }
+        if (acc_out) acc_out[r] = A.acc;
+        if (depth_out) depth_out[r] = A.depth;
+        if (disp_out) disp_out[r] = disp;
+      }
+      cur = nxt;
+    }
+    return;
+  }
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t r = it * ray_stride + (int64_t)blockIdx.x * RAYS_PER_BLOCK + threadIdx.x / SW;
     const bool live = r < R;
