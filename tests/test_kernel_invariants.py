@@ -1,0 +1,90 @@
+"""Static invariants of the built gfx950 code objects (no GPU needed): the properties DESIGN.md section 6 found to matter
+for the NeRF-MLP kernel -- no scratch in the kernel (a scratch reload waits on vmcnt, i.e. on the weight DMA in flight)
+and no compiler-inserted full DMA wait per slab step -- are checked on the ISA, so a toolchain or source change that
+brings either back fails here and not as a silent 3-10 % loss on the GPU box."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "nerf_sampling_amd", "libnerf_sampling_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _gfx950_code_objects(path):
+    """Every gfx950 device ELF in the library's clang offload bundles (one bundle per translation unit)."""
+    blob = open(path, "rb").read()
+    out, pos = [], 0
+    while True:
+        base = blob.find(MAGIC, pos)
+        if base < 0:
+            return out
+        (n,) = struct.unpack_from("<Q", blob, base + len(MAGIC))
+        p = base + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, p)
+            triple = blob[p + 24:p + 24 + tlen].decode()
+            p += 24 + tlen
+            if "gfx950" in triple and size:
+                out.append(blob[base + off:base + off + size])
+        pos = base + len(MAGIC)
+
+
+@pytest.fixture(scope="module")
+def nerf16_isa():
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    for co in _gfx950_code_objects(LIB):
+        if b"nerf_mlp_ob16_kernel" not in co:
+            continue
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name],
+                                 capture_output=True, text=True, check=True).stdout
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name],
+                                   capture_output=True, text=True, check=True).stdout
+        return dis, notes
+    pytest.fail("no gfx950 code object with nerf_mlp_ob16_kernel in the library")
+
+
+def _functions(dis):
+    """name -> instruction lines"""
+    out, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith("\t"):
+            cur.append(line.strip())
+    return out
+
+
+def test_nerf16_kernels_use_no_scratch_and_no_full_dma_wait(nerf16_isa):
+    dis, notes = nerf16_isa
+    fns = {k: v for k, v in _functions(dis).items() if "nerf_mlp_ob16_kernel" in k}
+    # the rays -> raw kernels (EMBEDDED = false: mangled "...ELb0EEE"), bf16 and f16, W = 256 and 128
+    main = {k: v for k, v in fns.items() if "ELb0EE" in k}
+    assert len(main) == 4, sorted(fns)
+    for name, ins in main.items():
+        text = "\n".join(ins)
+        assert "scratch_" not in text, f"{name}: scratch access in the kernel"
+        mfma = sum("v_mfma_f32_16x16x32" in i for i in ins)
+        full_waits = sum(bool(re.search(r"s_waitcnt vmcnt\(0\)(?! *lgkmcnt)|s_waitcnt vmcnt\(0\)$", i)) for i in ins)
+        dma = sum("global_load_lds_dwordx4" in i for i in ins)
+        assert mfma > 1000 and dma > 50
+        # the only full VMEM waits left are outside the slab loop (first-group staging, final drain); with the builtin
+        # LDS-DMA the compiler emitted one per slab step (92 in this kernel)
+        assert full_waits <= 10, f"{name}: {full_waits} s_waitcnt vmcnt(0)"
+    # kernel descriptors agree: no private segment for those kernels
+    for name in main:
+        m = re.search(re.escape(name) + r".*?\.private_segment_fixed_size:\s*(\d+)", notes, re.S)
+        if m:
+            assert int(m.group(1)) == 0
