@@ -270,6 +270,33 @@ def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
         assert (rms < tol).all(), (which, dtype, rms)
 
 
+@pytest.mark.parametrize("D,W,skip", [(2, 128, -1), (3, 256, 0), (5, 128, 3), (6, 256, 4), (7, 128, 1), (8, 256, -1), (9, 256, 4)])
+def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
+    """Program logic of the 16x16x32 kernel (two layers per trip + odd tail, skip at any depth or none, both widths,
+    ragged / tiny sample counts) against the k-major fp32 kernel, a different engine with a different stream layout:
+    agreement within 16-bit operand rounding."""
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+    from nerf_sampling_amd import synthetic
+
+    skips = () if skip < 0 else (skip,)
+    params = synthetic.make_nerf_params(seed=100 * D + skip + 7, D=D, W=W, skips=skips, hidden_gain=6 ** 0.5,
+                                        sigma_gain=30.0, spectral_decay=True)
+    net = NeRF(D=D, W=W, input_ch=63, input_ch_views=27, output_ch=5, skips=list(skips), use_viewdirs=True)
+    net.load_state_dict(params)
+    net = net.cuda()
+    gen = torch.Generator().manual_seed(D * 31 + W)
+    for R, N in ((1, 1), (3, 5), (37, 64), (130, 33)):
+        pts = (torch.rand(R, N, 3, generator=gen) * 4 - 2).cuda()
+        view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
+        ref = ops.nerf_forward(net.packed("f32"), pts, view).cpu().numpy()
+        scale = np.abs(ref).reshape(-1, 4).max(0) + 1e-6
+        for dtype, tol in (("bf16", 0.15), ("f16", 0.03)):   # max error over all samples; a wrong program gives O(1)
+            got = ops.nerf_forward(net.packed(dtype), pts, view).cpu().numpy()
+            assert got.shape == (R, N, 4) and np.isfinite(got).all()
+            err = np.abs(got - ref).reshape(-1, 4).max(0) / scale
+            assert (err < tol).all(), (D, W, skip, R, N, dtype, err)
+
+
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
 def test_nerf_forward_embedded_and_rays(ops, gpu_modules, golden, scene):
     g = golden("nerf_mlp")
