@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/sec at 800x800, DepthNet + 64 samples/ray (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N rank processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one full 800x800 frame of the reference's spiral render path (pose k of 40): ray generation,
@@ -15,12 +15,72 @@ Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--size", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--scene", default="lego_synth")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=50, help="rows of the frame timed on the CPU (x 800 rays)")
+    ap.add_argument("--mode", default="depthnet", choices=["depthnet", "full_nerf"],
+                    help="depthnet = BASELINE configs[1] (headline); full_nerf = configs[2], vanilla 64+128 coarse+fine")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a one-GPU box, all ranks sharing cuda:0)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without an outer launcher: start N fresh rank processes (one per GPU, RCCL rendezvous
+    on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches the GPU (it has not even imported torch), so
+    nothing is exec'ed or forked from a process with an initialised HIP runtime.  Any failing rank fails the run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NS_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # poll: a rank that dies early must not leave the others waiting in the rendezvous for ever
+    failed = False
+    while any(p_.poll() is None for p_ in procs):
+        if any(p_.poll() not in (None, 0) for p_ in procs):
+            failed = True
+            time.sleep(2.0)   # let the others report, then end them
+            for p_ in procs:
+                if p_.poll() is None:
+                    p_.kill()
+            break
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    rcs = [p_.wait() for p_ in procs]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if failed or any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    return 0
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _a = parse_args()
+    if _a.gpus > 1:
+        sys.exit(spawn_ranks(_a.gpus))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -94,25 +154,13 @@ def cpu_baseline(params, H, W, K, c2w, n_samples, rows, budget_s=20.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--size", type=int, default=800)
-    ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--scene", default="lego_synth")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=50, help="rows of the frame timed on the CPU (x 800 rays)")
-    ap.add_argument("--mode", default="depthnet", choices=["depthnet", "full_nerf"],
-                    help="depthnet = BASELINE configs[1] (headline); full_nerf = configs[2], vanilla 64+128 coarse+fine")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
-                    "the multi-rank path on a one-GPU box, all ranks sharing cuda:0)")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:   # checked before anything touches the GPU
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled number")
     n_dev = torch.cuda.device_count()
     dev_index = local_rank if (world > 1 and args.backend == "nccl") else min(local_rank, max(n_dev - 1, 0))
     if world > 1:
@@ -123,7 +171,9 @@ def main():
             dist.init_process_group(args.backend)
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rccl_world = dist.get_world_size() if world > 1 else 1
+    if rccl_world != args.gpus:
+        raise SystemExit(f"bench.py: process group has {rccl_world} ranks, --gpus {args.gpus}")
 
     from nerf_sampling_amd import ops, synthetic
     from nerf_sampling_amd.parallel import FrameRenderer, hip_row_renderer
@@ -208,7 +258,8 @@ def main():
         rays = H * W * args.steps
         out = {
             "metric": "rays/sec at 800x800, 64 samples/ray; PSNR vs reference",
-            "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": rays / elapsed, "unit": "rays/s", "n_gpus": world, "rccl_world": rccl_world,
+            "backend": args.backend if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "psnr_vs_fp32_path_db": psnr_db,
             "config": {"workload": (f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "

@@ -11,7 +11,8 @@
  * Conventions
  *   - every pointer marked "dev" is a device (HBM) pointer, fp32 unless stated; caller-owned
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are
- *     asynchronous on it and re-entrant across streams
+ *     asynchronous on it and re-entrant across streams (weight handles are read-only after packing and
+ *     own no per-call scratch; per-call intermediates live in the caller's workspace)
  *   - return value: 0 = ok, negative = NS_E_* below (nothing was launched), never throws
  *   - no torch types, no global state except lazily-queried device properties
  */
@@ -32,9 +33,9 @@ extern "C" {
 #define NS_E_NOMEM (-4)
 
 /* operand precision of the MFMA kernels (accumulation is always fp32) */
-#define NS_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact-fp32 parity path */
-#define NS_DTYPE_BF16 1 /* v_mfma_f32_32x32x16_bf16                        */
-#define NS_DTYPE_F16 2  /* v_mfma_f32_32x32x16_f16                         */
+#define NS_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact-fp32 parity path (k-major engine)             */
+#define NS_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16, both networks (output-sub-block-major engine)      */
+#define NS_DTYPE_F16 2  /* v_mfma_f32_16x16x32_f16, same engine                                         */
 
 /* sample placement modes, utils.py:220-244 */
 #define NS_MODE_DEPTH_ONLY 0
@@ -74,14 +75,30 @@ typedef struct ns_weights ns_weights; /* opaque */
 /* NeRF(D, W, input_ch=63, input_ch_views=27, skips=[skip], use_viewdirs=True)
  * (run_nerf_helpers.py:67-134).  w/b: arrays of D + 4 host pointers in the order
  * pts_linears.0..D-1, feature_linear, alpha_linear, views_linears.0, rgb_linear.
- * skip = index i after which the embedded input is re-concatenated (4), or -1 for none.     */
+ * skip = index i after which the embedded input is re-concatenated (4), or -1 for none.
+ * feature_linear (no activation) is composed with views_linears.0 at pack time, in fp64.   */
 int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* const* b, int dtype,
                  ns_weights** out);
-/* DepthNet(hidden_sizes=[width]*n_layers, cat_hidden_sizes=[width]*n_layers, multires=10)
- * (depth_net.py:10-169).  w/b: 4*n_layers + 1 host pointers in the order origin_layers.0..,
- * direction_layers.0.., intersection_layers.0.., cat_layers.0,2,.., to_depth.0.              */
+/* DepthNet(hidden_sizes, cat_hidden_sizes, multires=10) (depth_net.py:10-169).  w/b: 3*n_branch + n_trunk + 1
+ * host pointers in the order origin_layers.0.., direction_layers.0.., intersection_layers.0.., cat_layers.0,2,..,
+ * to_depth.0.  hidden_sizes [n_branch]: widths of the three skip branches (any); cat_sizes [n_trunk]: trunk widths,
+ * each <= 256 (class defaults [128]*6 / [128,128,128,128,256] and the production 10 x 256 both qualify).
+ * The skip branches are affine (the reference constructs nn.LeakyReLU(x) and never applies it, depth_net.py:140,148,
+ * 156), so the packer composes them with the first trunk layer, in fp64, into one 252 -> cat_sizes[0] layer; trunk
+ * layers are zero-padded to one width in {128, 256}.                                                          */
+int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, const int* cat_sizes,
+                        const float* const* w, const float* const* b, int dtype, ns_weights** out);
+/* the uniform case: hidden_sizes = cat_hidden_sizes = [width] * n_layers */
 int ns_pack_depthnet(int n_layers, int width, const float* const* w, const float* const* b,
                      int dtype, ns_weights** out);
+/* The pack-time folds on their own (HOST only, no device touched; tests check them against the literal chain):
+ * F_out [c0, 252] and bias_out [c0] of the folded DepthNet front end on cat[gamma(o), gamma(d), gamma(isect)]
+ * (w/b: the 3*n_branch branch tensors followed by cat_layers.0);                                              */
+int ns_fold_depthnet_front(int n_branch, const int* hidden_sizes, int c0, const float* const* w,
+                           const float* const* b, float* F_out, float* bias_out);
+/* w_out [W/2, W+27], b_out [W/2] of views_linears[0] o feature_linear (run_nerf_helpers.py:119-125)             */
+int ns_fold_nerf_views(int W, const float* w_feature, const float* b_feature, const float* w_views,
+                       const float* b_views, float* w_out, float* b_out);
 void ns_weights_destroy(ns_weights* w);
 /* bytes of the device weight stream (for roofline accounting) */
 int64_t ns_weights_stream_bytes(const ns_weights* w);

@@ -67,6 +67,9 @@ SIGNATURES = {
     "ns_posenc": (_i, [_p, _i64, _i, _i, _p, _p]),
     "ns_pack_nerf": (_i, [_i, _i, _i, _p, _p, _i, C.POINTER(_p)]),
     "ns_pack_depthnet": (_i, [_i, _i, _p, _p, _i, C.POINTER(_p)]),
+    "ns_pack_depthnet_ex": (_i, [_i, _p, _i, _p, _p, _p, _i, C.POINTER(_p)]),
+    "ns_fold_depthnet_front": (_i, [_i, _p, _i, _p, _p, _p, _p]),
+    "ns_fold_nerf_views": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "ns_weights_destroy": (None, [_p]),
     "ns_weights_stream_bytes": (_i64, [_p]),
     "ns_depthnet_forward": (_i, [_p, _p, _p, _i64, _f, _f, _f, _p, _p]),

@@ -238,7 +238,7 @@ class DepthNetFunction(torch.autograd.Function):
 
 
 def depthnet_forward_train(net, o: Tensor, d: Tensor) -> Tensor:
-    n, _width = net._check_supported()
+    n, _width = net._train_shape()
     mods = (list(net.origin_layers) + list(net.direction_layers) + list(net.intersection_layers)
             + [m for m in net.cat_layers if isinstance(m, torch.nn.Linear)] + [net.to_depth[0]])
     params = []

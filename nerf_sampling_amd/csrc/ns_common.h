@@ -26,6 +26,7 @@ inline int ew_grid(int64_t n, int block) {
 }
 
 int cu_count();
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 }  // namespace ns
 

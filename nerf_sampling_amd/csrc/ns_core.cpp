@@ -2,6 +2,9 @@
 #include "ns_common.h"
 
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace ns {
 
@@ -14,15 +17,35 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// per-device caches (a process may drive several GPUs; round-1 code cached the first device's answer)
+static std::mutex g_mu;
+static std::map<int, int> g_cus;
+static std::map<std::pair<const void*, int>, size_t> g_dyn_lds;
+
 int cu_count() {
-  static int cached = -1;
-  if (cached >= 0) return cached;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_cus.find(dev);
+  if (it != g_cus.end()) return it->second;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  cached = prop.multiProcessorCount;
-  return cached;
+  g_cus[dev] = prop.multiProcessorCount;
+  return prop.multiProcessorCount;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kernel` on the CURRENT device, raised whenever a launch needs more
+// than any earlier one did (the LDS size of the MLP kernels grows with the network depth through the bias image)
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_mu);
+  size_t& have = g_dyn_lds[std::make_pair(kernel, dev)];
+  if (bytes <= have) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e == hipSuccess) have = bytes;
+  return e;
 }
 
 }  // namespace ns

@@ -1,15 +1,11 @@
-// DepthNet forward (depth_net.py:117-169) as one persistent MFMA kernel: ray-sphere
-// intersection, three positional encodings, the three affine skip branches (the reference never
-// applies its LeakyReLU there, depth_net.py:140,148,156), the LeakyReLU trunk and the sigmoid
-// head.  One wave owns 32 rays; HBM traffic per ray is 24 B in, 4 B out (+ a per-workgroup stash
-// of two branch outputs that stays in L2).
+// DepthNet forward (depth_net.py:117-169), fp32 parity path, as one persistent MFMA kernel: ray-sphere
+// intersection, the three positional encodings, the FOLDED front end (the three affine skip branches -- the reference
+// never applies its LeakyReLU there, depth_net.py:140,148,156 -- composed with the first trunk layer at pack time,
+// ns_pack.hip), the LeakyReLU trunk and the sigmoid head.  One wave owns 32 rays; HBM traffic per ray is 24 B in,
+// 4 B out, nothing else.  The 16-bit paths run ns_depthnet_ob16.hip (v_mfma_f32_16x16x32).
 #include "ns_common.h"
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
-
-#ifndef NS_DN_WAVES
-#define NS_DN_WAVES 8   // waves per workgroup of the 16-bit W = 256 kernel (8: two per SIMD, prologue spills; 4: one per SIMD)
-#endif
 
 namespace {
 
@@ -20,48 +16,13 @@ struct DepthArgs {
   const float* bias;
   uint32_t n_slabs;
   int bias_floats;
-  int n_layers;
+  int n_layers;   // trunk layers (layer 0 is the folded 252 -> W one)
   const float* o;
   const float* d;
   int64_t R;
   float near_, far_, radius;
   float* z;
-  char* scratch;  // [grid][NWAVES][2][NB] blocks of 64 lanes
 };
-
-template <class M, int NB>
-__device__ __forceinline__ void stash_store(char* base, const typename M::Block (&hcur)[NB], int lane) {
-  using Block = typename M::Block;
-  static_for<NB>([&](auto b_) {
-    constexpr int b = decltype(b_)::value;
-    *reinterpret_cast<Block*>(base + (static_cast<size_t>(b) * 64 + lane) * sizeof(Block)) = hcur[b];
-  });
-}
-template <class M, int NB>
-__device__ __forceinline__ void stash_load(const char* base, typename M::Block (&hcur)[NB], int lane) {
-  using Block = typename M::Block;
-  static_for<NB>([&](auto b_) {
-    constexpr int b = decltype(b_)::value;
-    hcur[b] = *reinterpret_cast<const Block*>(base + (static_cast<size_t>(b) * 64 + lane) * sizeof(Block));
-  });
-}
-
-// one skip branch: h = e; layer 0 on cat[e, e]; layers >= 1 on cat[h, e]; no activation
-template <class M, int NB, int EBLK, class PipeT>
-__device__ __forceinline__ void branch(PipeT& ring, f32x16 (&acc)[NB], typename M::Block (&hcur)[NB],
-                                       const typename M::Block (&e)[EBLK], const float*& bias, int n_layers,
-                                       int h) {
-  init_bias<NB>(acc, bias, h); bias += NB * 32;
-  consume<M, NB, EBLK>(ring, acc, e);
-  consume<M, NB, EBLK>(ring, acc, e);
-  to_blocks<M, kNone, NB>(hcur, acc);
-  for (int i = 1; i < n_layers; ++i) {
-    init_bias<NB>(acc, bias, h); bias += NB * 32;
-    consume<M, NB, NB>(ring, acc, hcur);
-    consume<M, NB, EBLK>(ring, acc, e);
-    to_blocks<M, kNone, NB>(hcur, acc);
-  }
-}
 
 template <class M, int NB, int NWAVES, bool PRECISE_TRIG>
 __global__ void __launch_bounds__(NWAVES * 64)
@@ -79,9 +40,6 @@ depthnet_kernel(DepthArgs a) {
 
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
-
-  char* stash = a.scratch + (static_cast<size_t>(blockIdx.x) * NWAVES + wave) * 2 * NB * 64 * sizeof(Block);
-  constexpr size_t kStashBranch = static_cast<size_t>(NB) * 64 * sizeof(Block);
 
   const int64_t n_tiles = (a.R + 31) / 32;
   const int64_t n_groups = (n_tiles + NWAVES - 1) / NWAVES;
@@ -111,35 +69,22 @@ depthnet_kernel(DepthArgs a) {
     f32x16 acc[NB];
     Block hcur[NB];
     {
-      Block e3[2];
-      embed3<M, PRECISE_TRIG, 10, 2>(e3, o, h);
-      branch<M, NB, 2>(ring, acc, hcur, e3, bias, a.n_layers, h);
-      stash_store<M, NB>(stash, hcur, lane);
-      embed3<M, PRECISE_TRIG, 10, 2>(e3, d, h);
-      branch<M, NB, 2>(ring, acc, hcur, e3, bias, a.n_layers, h);
-      stash_store<M, NB>(stash + kStashBranch, hcur, lane);
-    }
-    {
-      Block e6[4];
-      embed6<M, PRECISE_TRIG>(e6, x6, h);
-      branch<M, NB, 4>(ring, acc, hcur, e6, bias, a.n_layers, h);
-      // trunk layer 0, K-segments in the order h_x, e_x, h_o, e_o, h_d, e_d
+      // folded layer 0 on cat[e_o, e_d, e_x]: 2 + 2 + 4 input blocks (252 -> 256 virtual features)
+      Block e[8];
+      {
+        Block e3[2];
+        embed3<M, PRECISE_TRIG, 10, 2>(e3, o, h);
+        e[0] = e3[0]; e[1] = e3[1];
+        embed3<M, PRECISE_TRIG, 10, 2>(e3, d, h);
+        e[2] = e3[0]; e[3] = e3[1];
+        Block e6[4];
+        embed6<M, PRECISE_TRIG>(e6, x6, h);
+        e[4] = e6[0]; e[5] = e6[1]; e[6] = e6[2]; e[7] = e6[3];
+      }
       init_bias<NB>(acc, bias, h); bias += NB * 32;
-      consume<M, NB, NB>(ring, acc, hcur);
-      consume<M, NB, 4>(ring, acc, e6);
+      consume<M, NB, 8>(ring, acc, e);
+      to_blocks<M, kLeaky, NB>(hcur, acc);
     }
-    {
-      Block e3[2];
-      stash_load<M, NB>(stash, hcur, lane);
-      consume<M, NB, NB>(ring, acc, hcur);
-      embed3<M, PRECISE_TRIG, 10, 2>(e3, o, h);
-      consume<M, NB, 2>(ring, acc, e3);
-      stash_load<M, NB>(stash + kStashBranch, hcur, lane);
-      consume<M, NB, NB>(ring, acc, hcur);
-      embed3<M, PRECISE_TRIG, 10, 2>(e3, d, h);
-      consume<M, NB, 2>(ring, acc, e3);
-    }
-    to_blocks<M, kLeaky, NB>(hcur, acc);
     for (int i = 1; i < a.n_layers; ++i) {
       init_bias<NB>(acc, bias, h); bias += NB * 32;
       consume<M, NB, NB>(ring, acc, hcur);
@@ -157,43 +102,32 @@ depthnet_kernel(DepthArgs a) {
 }
 
 int depthnet_program_slabs(int cpb, int NB, int n) {
-  auto br = [&](int eblk) {
-    return 2 * seg_slabs(cpb, NB, eblk) + (n - 1) * (seg_slabs(cpb, NB, NB) + seg_slabs(cpb, NB, eblk));
-  };
-  int s = 2 * br(2) + br(4);
-  s += 3 * seg_slabs(cpb, NB, NB) + seg_slabs(cpb, NB, 4) + 2 * seg_slabs(cpb, NB, 2);
-  s += (n - 1) * seg_slabs(cpb, NB, NB);
-  s += seg_slabs(cpb, 1, NB);
-  return s;
+  return seg_slabs(cpb, NB, 8) + (n - 1) * seg_slabs(cpb, NB, NB) + seg_slabs(cpb, 1, NB);
 }
 
 template <class M, int NB, int NWAVES, bool PRECISE>
-int launch(const ns_weights* net, DepthArgs& a, hipStream_t stream) {
+int launch(DepthArgs& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, NWAVES, 0>::kLdsBytes) + static_cast<size_t>(a.bias_floats) * 4;
   if (lds > 160 * 1024) {
     ns::set_error("ns_depthnet_forward: %zu bytes of LDS needed (too many layers for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
   }
   auto kern = depthnet_kernel<M, NB, NWAVES, PRECISE>;
-  NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(lds)));
+  NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.R + 31) / 32;
   const int64_t n_groups = (n_tiles + NWAVES - 1) / NWAVES;
   int cus = ns::cu_count();
   if (cus <= 0) cus = 256;
-  if (cus > kDepthnetMaxGrid) cus = kDepthnetMaxGrid;
   const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
-  const size_t need = static_cast<size_t>(grid) * NWAVES * 2 * NB * 64 * sizeof(typename M::Block);
-  if (need > net->scratch_bytes) {
-    ns::set_error("ns_depthnet_forward: stash too small (%zu > %zu)", need, net->scratch_bytes);
-    return NS_E_INVALID;
-  }
   kern<<<grid, NWAVES * 64, lds, stream>>>(a);
   NS_LAUNCH_CHECK();
   return NS_OK;
 }
 
 }  // namespace
+
+int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const float* d_dev, int64_t R, float near_,
+                             float far_, float sphere_radius, float* z_dev, hipStream_t stream);
 
 extern "C" {
 
@@ -203,11 +137,13 @@ int ns_depthnet_forward(const ns_weights* net, const float* o_dev, const float* 
   NS_REQUIRE(R >= 0, "bad shape");
   if (R == 0) return NS_OK;
   NS_REQUIRE(o_dev && d_dev && z_dev, "null pointer");
+  hipStream_t s = ns::as_stream(stream);
+  if (net->layout == 16) return ns_depthnet_forward_ob16(net, o_dev, d_dev, R, near_, far_, sphere_radius, z_dev, s);
+  NS_REQUIRE(net->dtype == NS_DTYPE_F32, "k-major DepthNet streams are fp32 only");
   const int NB = net->width / 32;
-  const int cpb = net->dtype == NS_DTYPE_F32 ? 4 : 2;
-  if (depthnet_program_slabs(cpb, NB, net->depth) != static_cast<int>(net->n_slabs)) {
+  if (depthnet_program_slabs(4, NB, net->depth) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_depthnet_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
-                  depthnet_program_slabs(cpb, NB, net->depth));
+                  depthnet_program_slabs(4, NB, net->depth));
     return NS_E_INVALID;
   }
   DepthArgs a{};
@@ -215,17 +151,7 @@ int ns_depthnet_forward(const ns_weights* net, const float* o_dev, const float* 
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
   a.n_layers = net->depth; a.o = o_dev; a.d = d_dev; a.R = R;
   a.near_ = near_; a.far_ = far_; a.radius = sphere_radius; a.z = z_dev;
-  a.scratch = static_cast<char*>(net->scratch_dev);
-  hipStream_t s = ns::as_stream(stream);
-  switch (net->dtype) {
-    case NS_DTYPE_F32:
-      return NB == 8 ? launch<MmaF32, 8, 4, true>(net, a, s) : launch<MmaF32, 4, 4, true>(net, a, s);
-    case NS_DTYPE_BF16:
-      return NB == 8 ? launch<MmaBF16, 8, NS_DN_WAVES, false>(net, a, s) : launch<MmaBF16, 4, 8, false>(net, a, s);
-    case NS_DTYPE_F16:
-      return NB == 8 ? launch<MmaF16, 8, NS_DN_WAVES, false>(net, a, s) : launch<MmaF16, 4, 8, false>(net, a, s);
-  }
-  return NS_E_UNSUPPORTED;
+  return NB == 8 ? launch<MmaF32, 8, 4, true>(a, s) : launch<MmaF32, 4, 4, true>(a, s);
 }
 
 }  // extern "C"

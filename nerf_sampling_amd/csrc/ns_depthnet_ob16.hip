@@ -1,0 +1,191 @@
+// DepthNet forward (depth_net.py:117-169) for the 16-bit operand paths (bf16 / f16) on the 16x16x32 engine of
+// ns_mlp_engine.h -- the same engine as the radiance-field kernel (ns_nerf_mlp_ob16.hip).  After the pack-time fold
+// (ns_pack.hip: the three affine skip branches and the first trunk layer are ONE 252 -> W layer) the network is a
+// plain MLP:  cat[gamma(o), gamma(d), gamma(sphere intersections)] (8 K-blocks) -> W, LeakyReLU -> ... -> 1, sigmoid.
+// A wave owns T = 4 tiles of 16 rays; activations never leave the register file; no global scratch, no spills.
+// HBM traffic per ray: 24 B in, 4 B out.
+#include "ns_common.h"
+#include "ns_mlp_engine.h"
+#include "ns_weights.h"
+
+namespace {
+
+using namespace nsmlp;
+
+constexpr int kT = 4;        // 16-ray tiles per wave
+constexpr int kWaves = 4;    // one wave per SIMD
+constexpr int kInKB = 8;     // K-blocks of the folded input layer: e_o (2), e_d (2), e_x (4)
+
+struct Depth16Args {
+  const char* stream;
+  const float* bias;
+  uint32_t n_slabs;
+  int bias_floats;
+  int n_layers;   // trunk layers; layer 0 is the folded 252 -> W one
+  const float* o;
+  const float* d;
+  int64_t R;
+  float near_, far_, radius;
+  float* z;
+};
+
+template <class M, int NKB>   // NKB = W / 32 K-blocks of a hidden layer
+__global__ void __launch_bounds__(kWaves * 64)
+depthnet_ob16_kernel(Depth16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int T = kT, NWAVES = kWaves, NSB = 2 * NKB;
+  using Block = typename M::Block;
+  using PipeT = Pipe<M, NWAVES, 0, kOb16Depth, kOb16Ahead>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+
+  // LDS: [weight ring][bias image][input staging: per wave 6 x 256 B]
+  float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
+  for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
+  __syncthreads();
+  const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(smem)));
+  const uint32_t stage_base = lds0 + PipeT::kLdsBytes + ((static_cast<uint32_t>(a.bias_floats) * 4u + 15u) & ~15u) +
+                              static_cast<uint32_t>(wave) * (6 * 256);
+
+  PipeT ring;
+  ring.init(a.stream, smem, a.n_slabs, wave, lane);
+
+  const int64_t n_tiles = (a.R + 15) / 16;
+  const int64_t n_groups = (n_tiles + NWAVES * T - 1) / (NWAVES * T);
+  auto ray_of = [&](int64_t grp, int t, int l16, bool& valid) -> int64_t {
+    const int64_t r = ((grp * NWAVES + wave) * T + t) * 16 + l16;
+    valid = r < a.R;
+    return valid ? r : a.R - 1;
+  };
+  // the NEXT group's rays are fetched by LDS-DMA right after layer 0 of the current one (no register is held across
+  // the network, no global-load wait -- which would also wait for the weight DMA in flight -- at a group boundary):
+  // lane j fetches the six values of the j-th of the wave's 64 consecutive rays; slots o 0..2, d 3..5
+  auto prefetch = [&](int64_t grp) {
+    bool valid;
+    const int64_t r = ray_of(grp, lane >> 4, lane & 15, valid);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lds_dma4(a.o + r * 3 + c, stage_base + c * 256);
+      lds_dma4(a.d + r * 3 + c, stage_base + (3 + c) * 256);
+    }
+  };
+  auto staged = [&](int t, int slot) -> float {
+    return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
+        static_cast<uintptr_t>(stage_base + slot * 256 + (t * 16 + n) * 4));
+  };
+
+  prefetch(blockIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    Block e[T][kInKB];
+    asm volatile("" ::: "memory");   // the staged inputs landed several slab steps ago (in-order vmcnt)
+    static_for<T>([&](auto t_) {
+      constexpr int t = decltype(t_)::value;
+      float o[3], d[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o[c] = staged(t, c); d[c] = staged(t, 3 + c); }
+      // ray-sphere intersections, utils.py:182-217 (NaN when the line misses, by design)
+      float x6[6];
+      {
+        const float b = 2.0f * ((d[0] * o[0] + d[1] * o[1]) + d[2] * o[2]);
+        const float on = sqrtf(__builtin_fmaf(o[2], o[2], __builtin_fmaf(o[1], o[1], o[0] * o[0])));  // torch.norm
+        const float c = on * on - a.radius * a.radius;
+        const float aa = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+        const float sq = sqrtf(b * b - 4.0f * aa * c);
+        const float t0 = (-b - sq) / (2.0f * aa), t1 = (-b + sq) / (2.0f * aa);
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) { x6[c3] = o[c3] + t0 * d[c3]; x6[3 + c3] = o[c3] + t1 * d[c3]; }
+      }
+      Block e3[2], e6[4];
+      embedN_16<M, false, 3, 10, 2>(e3, o, g);
+      e[t][0] = e3[0]; e[t][1] = e3[1];
+      embedN_16<M, false, 3, 10, 2>(e3, d, g);
+      e[t][2] = e3[0]; e[t][3] = e3[1];
+      embedN_16<M, false, 6, 10, 4>(e6, x6, g);
+      e[t][4] = e6[0]; e[t][5] = e6[1]; e[t][6] = e6[2]; e[t][7] = e6[3];
+    });
+
+    const float* bias = bias_lds;
+    Block hA[T][NKB], hB[T][NKB];
+    f32x4a last[T];
+    auto in_e = [&](auto t_, auto kb_) -> const Block& { return e[decltype(t_)::value][decltype(kb_)::value]; };
+    auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
+    auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
+
+    // layer 0 (folded): e -> hA
+    layer_ob16<M, T, NSB, kInKB, kLeaky>(ring, bias, g, hA, last, in_e);
+    convert_last16<M, kLeaky, T, NSB>(hA, last); bias += NSB * 16;
+    prefetch(grp + gridDim.x);   // clamped to the last ray past the end: loaded, never used
+    int l = 1;
+    for (; l + 1 < a.n_layers; l += 2) {   // two trunk layers per trip: hA -> hB -> hA
+      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
+      convert_last16<M, kLeaky, T, NSB>(hB, last); bias += NSB * 16;
+      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hA, last, in_B);
+      convert_last16<M, kLeaky, T, NSB>(hA, last); bias += NSB * 16;
+    }
+    if (l < a.n_layers) {  // odd layer left over: hA -> hB, then move back
+      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
+      convert_last16<M, kLeaky, T, NSB>(hB, last); bias += NSB * 16;
+      static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
+    }
+    // head (W -> 1): row 0 of a 16-row sub-block (lane group 0, register 0), sigmoid, z = near (1 - s) + far s
+    layer_ob16<M, T, 1, NKB, kNone>(ring, bias, g, hB, last, in_A);
+    if (g == 0) {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        bool valid;
+        const int64_t r = ray_of(grp, t, n, valid);
+        const float depth = 1.0f / (1.0f + expf(-last[t][0]));
+        if (valid) a.z[r] = a.near_ * (1.0f - depth) + a.far_ * depth;  // depth_net.py:168
+      });
+    }
+  }
+  ring.finish();
+}
+
+int depth16_program_slabs(int W, int n_layers) {
+  const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
+  return ob16_layer_slabs(NSB, kInKB, dp) + (n_layers - 1) * ob16_layer_slabs(NSB, NKB, dp) + ob16_layer_slabs(1, NKB, dp);
+}
+
+template <class M, int NKB>
+int launch(Depth16Args& a, hipStream_t stream) {
+  const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
+                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * 6 * 256;
+  if (lds > 160 * 1024) {
+    ns::set_error("ns_depthnet_forward: %zu bytes of LDS needed (too many layers for the resident bias image)", lds);
+    return NS_E_UNSUPPORTED;
+  }
+  auto kern = depthnet_ob16_kernel<M, NKB>;
+  NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
+  const int64_t n_tiles = (a.R + 15) / 16;
+  const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
+  int cus = ns::cu_count();
+  if (cus <= 0) cus = 256;
+  const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
+  kern<<<grid, kWaves * 64, lds, stream>>>(a);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+}  // namespace
+
+// called by ns_depthnet_forward for handles packed with layout 16 (arguments validated there)
+int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const float* d_dev, int64_t R, float near_,
+                             float far_, float sphere_radius, float* z_dev, hipStream_t stream) {
+  if (depth16_program_slabs(net->width, net->depth) != static_cast<int>(net->n_slabs)) {
+    ns::set_error("ns_depthnet_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
+                  depth16_program_slabs(net->width, net->depth));
+    return NS_E_INVALID;
+  }
+  Depth16Args a{};
+  a.stream = static_cast<const char*>(net->stream_dev);
+  a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
+  a.n_layers = net->depth; a.o = o_dev; a.d = d_dev; a.R = R;
+  a.near_ = near_; a.far_ = far_; a.radius = sphere_radius; a.z = z_dev;
+  const bool wide = net->width == 256;
+  if (net->dtype == NS_DTYPE_BF16) return wide ? launch<Mma16BF16, 8>(a, stream) : launch<Mma16BF16, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_F16) return wide ? launch<Mma16F16, 8>(a, stream) : launch<Mma16F16, 4>(a, stream);
+  return NS_E_UNSUPPORTED;
+}

@@ -591,20 +591,28 @@ __host__ __device__ constexpr int ob16_layer_slabs(int nsb, int nkb, int depth) 
   return (ob16_chunks(nsb, nkb, depth) + kSlabChunks - 1) / kSlabChunks;
 }
 
-// dword J (0..1) of the finished sub-block SB of one tile goes to dword 2 (SB & 1) + J of K-block SB >> 1
-template <class M, bool RELU, int SB, int J>
+// dword J (0..1) of the finished sub-block SB of one tile goes to dword 2 (SB & 1) + J of K-block SB >> 1.
+// ACT: kNone / kRelu (a packed signed-16-bit max after the conversion) / kLeaky (slope 0.01, on the fp32 values:
+// max(v, 0.01 v) == v > 0 ? v : 0.01 v for every finite v, and NaN stays NaN).
+template <class M, int ACT, int SB, int J>
 __device__ __forceinline__ void convert_piece16(typename M::Block& out, const f32x4a& c) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w = __builtin_bit_cast(u32x4, out.v);
-  w[2 * (SB & 1) + J] = M::template pack2<RELU>(c[2 * J], c[2 * J + 1]);
+  float a = c[2 * J], b = c[2 * J + 1];
+  if constexpr (ACT == kLeaky) {
+    a = __builtin_fmaxf(a, 0.01f * a);
+    b = __builtin_fmaxf(b, 0.01f * b);
+  }
+  w[2 * (SB & 1) + J] = M::template pack2<ACT == kRelu>(a, b);
   out.v = __builtin_bit_cast(typename M::AFrag, w);
 }
 
 // One layer: out[t][sb >> 1] <- act(bias + W . in) for the NSB 16-feature output sub-blocks but the last, whose raw
 // accumulators are returned in last[t] (heads read them; hidden layers convert_last16() them).
 //   in(t_, kb_) -> Block of tile t, K-block kb (compile-time indices); bias_lds: this layer's biases, natural order.
+//   ACT: activation of the converted sub-blocks (enum Act; `true` / `false` of older call sites = kRelu / kNone).
 // Stream order: for each sub-block, its NKB chunks (then zero chunks up to a multiple of the pipeline depth).
-template <class M, int T, int NSB, int NKB, bool RELU, class PipeT, class OutT, class InF>
+template <class M, int T, int NSB, int NKB, int ACT, class PipeT, class OutT, class InF>
 __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, int g, OutT& out, f32x4a (&last)[T], InF&& in) {
   constexpr int REAL = NSB * NKB;
   constexpr int TOTAL = ob16_chunks(NSB, NKB, PipeT::kDepth);
@@ -635,7 +643,7 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
           static_for<PPS>([&](auto i_) {
             constexpr int piece = kc * PPS + decltype(i_)::value;
             if constexpr (piece < PIECES)
-              convert_piece16<M, RELU, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
+              convert_piece16<M, ACT, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
           });
         }
         if constexpr (t == (T > 1 ? 1 : 0)) load_next();
@@ -650,11 +658,11 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
   });
   static_for<T>([&](auto t_) { last[decltype(t_)::value] = c[(NSB - 1) & 1][decltype(t_)::value]; });
 }
-template <class M, bool RELU, int T, int NSB, class OutT>
+template <class M, int ACT, int T, int NSB, class OutT>
 __device__ __forceinline__ void convert_last16(OutT& out, const f32x4a (&last)[T]) {
   static_for<T>([&](auto t_) {
     static_for<2>([&](auto j_) {
-      convert_piece16<M, RELU, NSB - 1, decltype(j_)::value>(out[decltype(t_)::value][(NSB - 1) >> 1], last[decltype(t_)::value]);
+      convert_piece16<M, ACT, NSB - 1, decltype(j_)::value>(out[decltype(t_)::value][(NSB - 1) >> 1], last[decltype(t_)::value]);
     });
   });
 }
@@ -705,6 +713,72 @@ __device__ __forceinline__ void embed3_16(typename M::Block (&out)[NKB], float p
     });
     out[kb] = M::from_f32(x);
   });
+}
+// NC-component, L-level embedding of one ray into NKB K-blocks, same slot scheme as embed3_16: the lane's element e of
+// K-block kb is slot q = 16 kb + 8 u + e (g = 2u + c); q < NC L: level q / NC, component q % NC, sine (c = 0) or cosine
+// (c = 1); then the raw components two per slot, slot NC L + j: x_j (c = 0) / x_{HALF + j} (c = 1), HALF = ceil(NC / 2);
+// beyond: pad.  (NC = 3 reproduces embed3_16; the DepthNet's sphere intersections are NC = 6, L = 10: 4 K-blocks.)
+template <class M, bool PRECISE, int NC, int L, int NKB>
+__device__ __forceinline__ void embedN_16(typename M::Block (&out)[NKB], const float (&p)[NC], int g) {
+  constexpr int HALF = (NC + 1) / 2;
+  Rev r[NC];
+  static_for<NC>([&](auto i_) { r[decltype(i_)::value] = to_rev(p[decltype(i_)::value]); });
+  const bool u = (g >> 1) != 0;
+  const int c = g & 1;
+  auto trig = [&](float hi, float lo, int level) -> float {
+    Trig<PRECISE> t(0.0f);
+    t.r.hi = hi; t.r.lo = lo;
+    return t(level, c);
+  };
+  static_for<NKB>([&](auto kb_) {
+    constexpr int kb = decltype(kb_)::value;
+    float x[8];
+    static_for<8>([&](auto e_) {
+      constexpr int e = decltype(e_)::value;
+      constexpr int q0 = 16 * kb + e, q1 = q0 + 8;       // the slot for u = 0 and for u = 1
+      auto value = [&](auto q_) -> float {               // non-trigonometric slots (values, never addresses)
+        constexpr int j = decltype(q_)::value - NC * L;
+        if constexpr (j >= 0 && j < HALF) {
+          const float a = p[j];
+          if constexpr (HALF + j < NC) { const float b = p[HALF + j]; return c ? b : a; }
+          else return c ? 0.0f : a;
+        } else {
+          return 0.0f;
+        }
+      };
+      using Q0 = std::integral_constant<int, q0>;
+      using Q1 = std::integral_constant<int, q1>;
+      if constexpr (q1 < NC * L) {                        // both candidates are sin/cos slots: one evaluation
+        const float h0 = r[q0 % NC].hi, h1 = r[q1 % NC].hi, l0 = r[q0 % NC].lo, l1 = r[q1 % NC].lo;
+        const float hi = u ? h1 : h0;
+        const float lo = u ? l1 : l0;
+        x[e] = trig(hi, lo, u ? q1 / NC : q0 / NC);
+      } else if constexpr (q0 < NC * L) {
+        const float tv = trig(r[q0 % NC].hi, r[q0 % NC].lo, q0 / NC);
+        const float ov = value(Q1{});
+        x[e] = u ? ov : tv;
+      } else {
+        const float a = value(Q0{}), b = value(Q1{});
+        x[e] = u ? b : a;
+      }
+    });
+    out[kb] = M::from_f32(x);
+  });
+}
+// reference column of feature index k of an embedN_16 segment (column order run_nerf_helpers.py:44-45), or -1
+__host__ __device__ inline int embedN_col16(int k, int NC, int L) {
+  const int kb = k >> 5, r = k & 31;
+  const int e = (r & 3) + 4 * (r >> 4), g = (r >> 2) & 3;     // inverse of feature16()
+  const int u = g >> 1, c = g & 1;
+  const int q = 16 * kb + 8 * u + e;
+  const int half = (NC + 1) / 2;
+  if (q < NC * L) return NC + 2 * NC * (q / NC) + NC * c + (q % NC);
+  const int j = q - NC * L;
+  if (j < half) {
+    if (c == 0) return j;
+    return half + j < NC ? half + j : -1;
+  }
+  return -1;
 }
 // reference column (run_nerf_helpers.py:44-45 order) of feature index k of an embed3_16 segment, or -1 for padding
 __host__ __device__ inline int embed3_col16(int k, int L) {

@@ -1,6 +1,6 @@
 // Radiance-field MLP forward (run_network + NeRF.forward, Trainer.py:789-806 and
 // run_nerf_helpers.py:67-134) as ONE persistent MFMA kernel: positional encoding of points and
-// view directions, 8x256 trunk with the input skip, sigma head, feature/view/rgb head.
+// view directions, 8x256 trunk with the input skip, sigma head, (feature o view) / rgb head.
 // Per 32-sample tile nothing but 12 B of point, 12 B of direction and 16 B of output touches HBM;
 // the 1.2 MB (bf16) weight stream is re-read from L2 by every workgroup through the LDS ring.
 #include "ns_common.h"
@@ -98,11 +98,8 @@ nerf_mlp_kernel(NerfArgs a) {
     init_bias<1>(acc1, bias, h); bias += 32;
     consume<M, 1, NB>(ring, acc1, hcur);
     const float sigma = acc1[0][0];
-    // feature (W -> W, no activation)
-    init_bias<NB>(acc, bias, h); bias += NB * 32;
-    consume<M, NB, NB>(ring, acc, hcur);
-    to_blocks<M, kNone, NB>(hcur, acc);
-    // views: cat[feature, dirs27] -> W/2, relu
+    // views o feature: cat[h, dirs27] -> W/2, relu (feature_linear has no activation and is folded into
+    // views_linears[0] at pack time, ns_pack.hip)
     f32x16 accv[NB / 2];
     Block hv[NB / 2];
     init_bias<NB / 2>(accv, bias, h); bias += (NB / 2) * 32;
@@ -128,8 +125,7 @@ int nerf_program_slabs(int cpb, int NB, int D, int skip) {
     if (l - 1 == skip) n += seg_slabs(cpb, NB, 2);
     n += seg_slabs(cpb, NB, NB);
   }
-  n += seg_slabs(cpb, 1, NB) + seg_slabs(cpb, NB, NB) + seg_slabs(cpb, NB / 2, NB) +
-       seg_slabs(cpb, NB / 2, 1) + seg_slabs(cpb, 1, NB / 2);
+  n += seg_slabs(cpb, 1, NB) + seg_slabs(cpb, NB / 2, NB) + seg_slabs(cpb, NB / 2, 1) + seg_slabs(cpb, 1, NB / 2);
   return n;
 }
 
@@ -137,12 +133,7 @@ template <class M, int NB, int NWAVES, int LAG, bool PRECISE, bool EMB>
 int launch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, NWAVES, LAG>::kLdsBytes) + static_cast<size_t>(a.bias_floats) * 4;
   auto kern = nerf_mlp_kernel<M, NB, NWAVES, LAG, PRECISE, EMB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(lds)));
-    attr_set = true;
-  }
+  NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 31) / 32;
   const int64_t n_groups = (n_tiles + NWAVES - 1) / NWAVES;
   int cus = ns::cu_count();

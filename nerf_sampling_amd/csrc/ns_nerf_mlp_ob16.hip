@@ -2,7 +2,7 @@
 // sustains the most under the MI355X power cap (tools/mfma_peak.hip: 2.14 vs 1.87 PFLOP/s for 32x32x16 with live
 // operands).  Same operator as ns_nerf_mlp.hip (run_network + NeRF.forward, Trainer.py:789-806 and
 // run_nerf_helpers.py:67-134): positional encoding of points and view directions, DxW trunk with the input skip,
-// sigma head, feature/view/rgb head, one persistent kernel.  A wave owns T = 4 tiles of 16 samples (64 samples);
+// (feature o view) layer carrying the sigma head as one extra output row, rgb head, one persistent kernel.  A wave owns T = 4 tiles of 16 samples (64 samples);
 // every A fragment (16 output rows x 32 input features, 1 KiB) read from LDS feeds 4 MFMAs; layers are walked one
 // 16-row output sub-block at a time (layer_ob16 in ns_mlp_engine.h; weight stream layout 16 of ns_pack.hip).
 #include "ns_common.h"
@@ -169,22 +169,18 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
     }
-    // sigma head (W -> 1): row 0 of a 16-row sub-block (lane group 0, register 0)
-    float sigma[T];
-    layer_ob16<M, T, 1, NKB, false>(ring, bias, g, hB, last, in_A); bias += 16;
-    static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
-    // feature (W -> W, no activation): hA -> hB
-    layer_ob16<M, T, NSB, NKB, false>(ring, bias, g, hB, last, in_A); bias += NSB * 16;
-    convert_last16<M, false, T, NSB>(hB, last);
-    // views: cat[feature, dirs27] -> W/2, relu: (hB, ve) -> hA[0 .. NKB/2)
-    auto in_Bv = [&](auto t_, auto kb_) -> Block {
+    // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
+    // cat[h, dirs27] -> W/2, relu: (hA, ve) -> hB[0 .. NKB/2); alpha_linear rides along as row 0 of one extra, LAST
+    // sub-block, whose raw accumulators come back in `last`: sigma = row 0 (lane group 0, register 0)
+    auto in_Av = [&](auto t_, auto kb_) -> Block {
       constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
+      if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
     };
-    layer_ob16<M, T, NSB / 2, NKB + 1, true>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2) * 16;
-    convert_last16<M, true, T, NSB / 2>(hA, last);
+    float sigma[T];
+    layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
+    static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
     // rgb (W/2 -> 3): rows 0..2 (lane group 0, registers 0..2)
-    layer_ob16<M, T, 1, NKB / 2, false>(ring, bias, g, hB, last, in_A);
+    layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
 
     if (g == 0) {
       static_for<T>([&](auto t_) {
@@ -202,8 +198,7 @@ int ob16_program_slabs(int W, int D, int skip) {
   const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
   int n = ob16_layer_slabs(NSB, 2, dp);
   for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, (l - 1 == skip) ? NKB + 2 : NKB, dp);
-  n += ob16_layer_slabs(1, NKB, dp) + ob16_layer_slabs(NSB, NKB, dp) + ob16_layer_slabs(NSB / 2, NKB + 1, dp) +
-       ob16_layer_slabs(1, NKB / 2, dp);
+  n += ob16_layer_slabs(NSB / 2 + 1, NKB + 1, dp) + ob16_layer_slabs(1, NKB / 2, dp);
   return n;
 }
 
@@ -213,12 +208,7 @@ int launch(Nerf16Args& a, hipStream_t stream) {
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
                      static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash | input staging
   auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               static_cast<int>(lds)));
-    attr_set = true;
-  }
+  NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
   const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
   int cus = ns::cu_count();

@@ -1,11 +1,21 @@
 // Host-side packers: reference state-dict tensors -> MFMA weight stream + bias image.
 //
-// The stream is the exact sequence of 1-KiB A-operand chunks the kernels in ns_nerf_mlp.hip /
-// ns_depthnet.hip consume (see ns_mlp_engine.h).  The "program" below (order of segment()
-// calls) must mirror the order of consume<>() calls in those kernels one for one.
+// The stream is the exact sequence of 1-KiB A-operand chunks the kernels in ns_nerf_mlp*.hip /
+// ns_depthnet*.hip consume (see ns_mlp_engine.h).  The "program" below (order of segment() /
+// layer_ob16() calls) must mirror the order of consume<>() / layer_ob16<>() calls in those kernels one for one.
+//
+// Affine stretches of the reference networks are composed here, once, in fp64 ("folding"):
+//   * DepthNet: the three skip branches never apply their activation (depth_net.py:136-160 constructs
+//     nn.LeakyReLU(x) and drops it), so each is one affine map of its embedding, and together with the first trunk
+//     layer (depth_net.py:158-163) the whole front end is ONE 252 -> C0 layer on cat[e_o, e_d, e_x].
+//   * NeRF: feature_linear has no activation and feeds views_linears[0] directly (run_nerf_helpers.py:119-125), so
+//     W_views[:, :W] . W_feature is one (W + 27) -> W/2 layer.
+// The kernels then execute 19.6 % (DepthNet) / 89 % (NeRF) of the reference's MACs; the result differs from the
+// reference's own fp32 chain by rounding only (the fp64 composition is the more exact of the two).
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <utility>
 #include <vector>
 
 #include "ns_common.h"
@@ -137,6 +147,118 @@ struct Builder {
   }
 };
 
+
+// ---- fp64 composition of affine stretches -----------------------------------------------------------
+struct Affine {   // y = A x + c, A row-major [out, in]
+  int out = 0, in = 0;
+  std::vector<double> A, c;
+};
+
+// One DepthNet skip branch (depth_net.py:136-156): h = e; layer 0 on cat[e, e]; layers i >= 1 on cat[h, e]; no
+// activation.  w[i] is [hs[i], (i ? hs[i-1] : E) + E] row-major.
+Affine fold_branch(const float* const* w, const float* const* b, int n, const int* hs, int E) {
+  Affine f;
+  f.out = hs[0]; f.in = E;
+  f.A.assign(static_cast<size_t>(hs[0]) * E, 0.0);
+  f.c.assign(hs[0], 0.0);
+  for (int r = 0; r < hs[0]; ++r) {
+    const float* row = w[0] + static_cast<size_t>(r) * 2 * E;
+    for (int k = 0; k < E; ++k) f.A[static_cast<size_t>(r) * E + k] = static_cast<double>(row[k]) + static_cast<double>(row[E + k]);
+    f.c[r] = b[0][r];
+  }
+  for (int i = 1; i < n; ++i) {
+    const int H = hs[i - 1], O = hs[i], in_f = H + E;
+    Affine g;
+    g.out = O; g.in = E;
+    g.A.assign(static_cast<size_t>(O) * E, 0.0);
+    g.c.assign(O, 0.0);
+    for (int r = 0; r < O; ++r) {
+      const float* row = w[i] + static_cast<size_t>(r) * in_f;
+      double* dst = g.A.data() + static_cast<size_t>(r) * E;
+      double cc = b[i][r];
+      for (int j = 0; j < H; ++j) {
+        const double wj = row[j];
+        const double* src = f.A.data() + static_cast<size_t>(j) * E;
+        for (int k = 0; k < E; ++k) dst[k] += wj * src[k];
+        cc += wj * f.c[j];
+      }
+      for (int k = 0; k < E; ++k) dst[k] += static_cast<double>(row[H + k]);
+      g.c[r] = cc;
+    }
+    f = std::move(g);
+  }
+  return f;
+}
+
+// dst[r, dst_col0 + k] (+)= sum_j T[r, t_col0 + j] * f.A[j, k];  bias[r] += sum_j T[r, t_col0 + j] * f.c[j]
+void compose_into(std::vector<double>& dst, int dst_ld, int dst_col0, std::vector<double>& bias, const float* T, int t_ld,
+                  int t_col0, int rows, const Affine& f) {
+  for (int r = 0; r < rows; ++r) {
+    const float* trow = T + static_cast<size_t>(r) * t_ld + t_col0;
+    double* d = dst.data() + static_cast<size_t>(r) * dst_ld + dst_col0;
+    double cc = 0.0;
+    for (int j = 0; j < f.out; ++j) {
+      const double tj = trow[j];
+      const double* src = f.A.data() + static_cast<size_t>(j) * f.in;
+      for (int k = 0; k < f.in; ++k) d[k] += tj * src[k];
+      cc += tj * f.c[j];
+    }
+    bias[r] += cc;
+  }
+}
+
+std::vector<float> to_f32(const std::vector<double>& v) {
+  std::vector<float> o(v.size());
+  for (size_t i = 0; i < v.size(); ++i) o[i] = static_cast<float>(v[i]);
+  return o;
+}
+
+
+// views(cat[feature(h), dirs]) = (Wv[:, :W] Wf) h + Wv[:, W:] dirs + (Wv[:, :W] bf + bv): one (W + 27) -> W/2 layer
+// (run_nerf_helpers.py:119-125: no activation between feature_linear and views_linears[0]), composed in fp64
+void fold_nerf_views(int W, const float* Wf, const float* bfeat, const float* Wv, const float* bv,
+                     std::vector<float>& wvf, std::vector<float>& bvf) {
+  const int HV = W / 2, KV = W + 27;
+  std::vector<double> acc(static_cast<size_t>(HV) * KV, 0.0), bb(HV, 0.0);
+  for (int r = 0; r < HV; ++r) {
+    const float* vrow = Wv + static_cast<size_t>(r) * KV;
+    double* dst = acc.data() + static_cast<size_t>(r) * KV;
+    double cc = bv[r];
+    for (int j = 0; j < W; ++j) {
+      const double vj = vrow[j];
+      const float* frow = Wf + static_cast<size_t>(j) * W;
+      for (int k = 0; k < W; ++k) dst[k] += vj * static_cast<double>(frow[k]);
+      cc += vj * static_cast<double>(bfeat[j]);
+    }
+    for (int k = W; k < KV; ++k) dst[k] = vrow[k];
+    bb[r] = cc;
+  }
+  wvf = to_f32(acc);
+  bvf = to_f32(bb);
+}
+
+// DepthNet front end: the three affine skip branches (depth_net.py:136-156) composed with the first trunk layer on
+// cat[h_o, h_d, h_x, e_o, e_d, e_x] (depth_net.py:158-163) -> F [C0, 252] on cat[e_o, e_d, e_x], fb [C0]
+void fold_depthnet_front(int n_branch, const int* hidden_sizes, int C0, const float* const* w, const float* const* b,
+                         std::vector<float>& F32, std::vector<float>& fb32) {
+  const int E3 = 63, E6 = 126, EIN = E3 + E3 + E6;
+  const Affine fo = fold_branch(w, b, n_branch, hidden_sizes, E3);
+  const Affine fd = fold_branch(w + n_branch, b + n_branch, n_branch, hidden_sizes, E3);
+  const Affine fx = fold_branch(w + 2 * n_branch, b + 2 * n_branch, n_branch, hidden_sizes, E6);
+  const int HL = hidden_sizes[n_branch - 1], t0 = 3 * n_branch, inT = 3 * HL + EIN;
+  std::vector<double> F(static_cast<size_t>(C0) * EIN, 0.0), fb(C0, 0.0);
+  for (int r = 0; r < C0; ++r) {
+    const float* row = w[t0] + static_cast<size_t>(r) * inT + 3 * HL;
+    for (int k = 0; k < EIN; ++k) F[static_cast<size_t>(r) * EIN + k] = row[k];
+    fb[r] = b[t0][r];
+  }
+  compose_into(F, EIN, 0, fb, w[t0], inT, 0, C0, fo);
+  compose_into(F, EIN, E3, fb, w[t0], inT, HL, C0, fd);
+  compose_into(F, EIN, 2 * E3, fb, w[t0], inT, 2 * HL, C0, fx);
+  F32 = to_f32(F);
+  fb32 = to_f32(fb);
+}
+
 int finish(Builder& b, ns_weights* w) {
   w->n_slabs = static_cast<uint32_t>(b.bytes.size() / kSlabBytes);
   w->bias_floats = static_cast<int>(b.bias.size());
@@ -171,6 +293,9 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   auto ident = [](int k) { return k; };
   auto xcol = [](int k) { return nsmlp::embed3_col(k, 10); };
   const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;   // 0 = k-major (fp32 kernel); 16 = 16x16x32 engine (bf16 / f16)
+  const int HV = W / 2, KV = W + 27;
+  std::vector<float> wvf, bvf;
+  fold_nerf_views(W, w[D], b[D], w[D + 2], b[D + 2], wvf, bvf);
   if (layout == 0) {
     // layer 0: 63 -> W
     bl.add_bias(b[0], W, NB);
@@ -186,14 +311,12 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     }
     const float* const* wf = w + D;
     const float* const* bf = b + D;
-    // alpha (W -> 1), feature (W -> W), views ([feature, dirs27] -> W/2), rgb (W/2 -> 3)
+    // alpha (W -> 1), views o feature folded ([h, dirs27] -> W/2), rgb (W/2 -> 3)
     bl.add_bias(bf[1], 1, 1);
     bl.segment(wf[1], 1, W, 1, NB, ident);
-    bl.add_bias(bf[0], W, NB);
-    bl.segment(wf[0], W, W, NB, NB, ident);
-    bl.add_bias(bf[2], W / 2, NB / 2);
-    bl.segment(wf[2], W / 2, W + 27, NB / 2, NB, ident);
-    bl.segment(wf[2], W / 2, W + 27, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
+    bl.add_bias(bvf.data(), HV, NB / 2);
+    bl.segment(wvf.data(), HV, KV, NB / 2, NB, ident);
+    bl.segment(wvf.data(), HV, KV, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
     bl.add_bias(bf[3], 3, 1);
     bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
   } else if (layout == 16) {
@@ -211,14 +334,18 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     }
     const float* const* wf = w + D;
     const float* const* bf = b + D;
-    bl.add_bias16(bf[1], 1, 1);
-    bl.layer_ob16(wf[1], 1, W, 1, {{NKB, ident}});
-    bl.add_bias16(bf[0], W, NSB);
-    bl.layer_ob16(wf[0], W, W, NSB, {{NKB, ident}});
-    bl.add_bias16(bf[2], W / 2, NSB / 2);
-    bl.layer_ob16(wf[2], W / 2, W + 27, NSB / 2,
+    // views o feature (folded) with alpha_linear riding along as row W/2, i.e. row 0 of one extra 16-row sub-block
+    // whose raw accumulators the kernel reads as sigma (no activation: it is the layer's LAST sub-block)
+    (void)bf;
+    std::vector<float> wc(static_cast<size_t>(HV + 1) * KV, 0.0f), bc(HV + 1, 0.0f);
+    std::memcpy(wc.data(), wvf.data(), wvf.size() * sizeof(float));
+    std::memcpy(bc.data(), bvf.data(), bvf.size() * sizeof(float));
+    std::memcpy(wc.data() + static_cast<size_t>(HV) * KV, wf[1], static_cast<size_t>(W) * sizeof(float));
+    bc[HV] = b[D + 1][0];
+    bl.add_bias16(bc.data(), HV + 1, NSB / 2 + 1);
+    bl.layer_ob16(wc.data(), HV + 1, KV, NSB / 2 + 1,
                   {{NKB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col16(k, 4); return c < 0 ? -1 : W + c; }}});
-    bl.add_bias16(bf[3], 3, 1);
+    bl.add_bias16(b[D + 3], 3, 1);
     bl.layer_ob16(wf[3], 3, W / 2, 1, {{NKB / 2, ident}});
   }
 
@@ -231,68 +358,105 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   return NS_OK;
 }
 
-int ns_pack_depthnet(int n_layers, int width, const float* const* w, const float* const* b, int dtype,
-                     ns_weights** out) {
-  NS_REQUIRE(out && w && b, "null pointer");
+int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, const int* cat_sizes,
+                        const float* const* w, const float* const* b, int dtype, ns_weights** out) {
+  NS_REQUIRE(out && w && b && hidden_sizes && cat_sizes, "null pointer");
   *out = nullptr;
-  if (!(width == 128 || width == 256) || n_layers < 1 || n_layers > 64 ||
+  if (n_branch < 1 || n_branch > 64 || n_trunk < 1 || n_trunk > 64 ||
       !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16)) {
-    ns::set_error("ns_pack_depthnet: unsupported network (width=%d n_layers=%d dtype=%d); kernels exist for "
-                  "uniform hidden width in {128,256}, multires 10", width, n_layers, dtype);
+    ns::set_error("ns_pack_depthnet: unsupported network (n_branch=%d n_trunk=%d dtype=%d)", n_branch, n_trunk, dtype);
     return NS_E_UNSUPPORTED;
   }
-  for (int i = 0; i < 4 * n_layers + 1; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
-  const int W = width, NB = W / 32, n = n_layers;
-  Builder bl(dtype);
-  auto ident = [](int k) { return k; };
-  auto col3 = [](int k) { return nsmlp::embed3_col(k, 10); };
-  auto col6 = [](int k) { return nsmlp::embed6_col(k); };
-  // skip branches (depth_net.py:136-156): layer 0 sees cat[e, e], layers >= 1 cat[h, e]
-  auto branch = [&](int first, int eblk, int ecols, const std::function<int(int)>& ecol) {
-    bl.add_bias(b[first], W, NB);
-    bl.segment(w[first], W, 2 * ecols, NB, eblk, ecol);
-    bl.segment(w[first], W, 2 * ecols, NB, eblk, [&](int k) { const int c = ecol(k); return c < 0 ? -1 : ecols + c; });
-    for (int i = 1; i < n; ++i) {
-      bl.add_bias(b[first + i], W, NB);
-      bl.segment(w[first + i], W, W + ecols, NB, NB, ident);
-      bl.segment(w[first + i], W, W + ecols, NB, eblk, [&](int k) { const int c = ecol(k); return c < 0 ? -1 : W + c; });
-    }
-  };
-  branch(0, 2, 63, col3);          // origin
-  branch(n, 2, 63, col3);          // direction
-  branch(2 * n, 4, 126, col6);     // sphere intersections
-  // trunk layer 0 on cat[h_o, h_d, h_x, e_o, e_d, e_x] (depth_net.py:158-163); the kernel consumes
-  // the K-segments in the order h_x, e_x, h_o, e_o, h_d, e_d
-  const int t0 = 3 * n, inT = 3 * W + 252;
-  bl.add_bias(b[t0], W, NB);
-  bl.segment(w[t0], W, inT, NB, NB, [W](int k) { return 2 * W + k; });
-  bl.segment(w[t0], W, inT, NB, 4, [&](int k) { const int c = col6(k); return c < 0 ? -1 : 3 * W + 126 + c; });
-  bl.segment(w[t0], W, inT, NB, NB, ident);
-  bl.segment(w[t0], W, inT, NB, 2, [&](int k) { const int c = col3(k); return c < 0 ? -1 : 3 * W + c; });
-  bl.segment(w[t0], W, inT, NB, NB, [W](int k) { return W + k; });
-  bl.segment(w[t0], W, inT, NB, 2, [&](int k) { const int c = col3(k); return c < 0 ? -1 : 3 * W + 63 + c; });
-  for (int i = 1; i < n; ++i) {
-    bl.add_bias(b[t0 + i], W, NB);
-    bl.segment(w[t0 + i], W, W, NB, NB, ident);
+  int cmax = 0;
+  for (int i = 0; i < n_branch; ++i) NS_REQUIRE(hidden_sizes[i] >= 1 && hidden_sizes[i] <= 4096, "bad hidden size");
+  for (int i = 0; i < n_trunk; ++i) {
+    NS_REQUIRE(cat_sizes[i] >= 1, "bad trunk size");
+    if (cat_sizes[i] > cmax) cmax = cat_sizes[i];
   }
-  bl.add_bias(b[4 * n], 1, 1);
-  bl.segment(w[4 * n], 1, W, 1, NB, ident);
+  if (cmax > 256) {
+    ns::set_error("ns_pack_depthnet: trunk layers wider than 256 (%d) have no kernel (multires 10, trunk widths <= 256)", cmax);
+    return NS_E_UNSUPPORTED;
+  }
+  const int n_tensors = 3 * n_branch + n_trunk + 1;
+  for (int i = 0; i < n_tensors; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
+  const int E3 = 63, E6 = 126, EIN = E3 + E3 + E6;   // embeddings of origin, direction, sphere intersections: 252
+  // 1 + 2. the three affine skip branches composed into the first trunk layer, in fp64
+  const int t0 = 3 * n_branch, C0 = cat_sizes[0];
+  std::vector<float> F32, fb32;
+  fold_depthnet_front(n_branch, hidden_sizes, C0, w, b, F32, fb32);
+
+  // 3. the stream: layer 0 (252 -> Wp), trunk layers 1.. (Wp -> Wp), head (Wp -> 1); every trunk layer is zero-padded
+  //    to ONE width Wp in {128, 256}: a padded row has zero weights and bias, LeakyReLU(0) = 0 feeds zero columns
+  const int W = cmax <= 128 ? 128 : 256, NB = W / 32;
+  const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;
+  Builder bl(dtype);
+  auto padded_ident = [](int in_f) { return [in_f](int k) { return k < in_f ? k : -1; }; };
+  if (layout == 0) {
+    // k-major (fp32): input blocks e_o (2), e_d (2), e_x (4) in the slot order of embed3 / embed6
+    auto col3 = [](int k) { return nsmlp::embed3_col(k, 10); };
+    bl.add_bias(fb32.data(), C0, NB);
+    bl.segment(F32.data(), C0, EIN, NB, 8, [&](int k) {
+      if (k < 64) return col3(k);
+      if (k < 128) { const int c = col3(k - 64); return c < 0 ? -1 : E3 + c; }
+      const int c = nsmlp::embed6_col(k - 128);
+      return c < 0 ? -1 : 2 * E3 + c;
+    });
+    for (int i = 1; i < n_trunk; ++i) {
+      bl.add_bias(b[t0 + i], cat_sizes[i], NB);
+      bl.segment(w[t0 + i], cat_sizes[i], cat_sizes[i - 1], NB, NB, padded_ident(cat_sizes[i - 1]));
+    }
+    bl.add_bias(b[t0 + n_trunk], 1, 1);
+    bl.segment(w[t0 + n_trunk], 1, cat_sizes[n_trunk - 1], 1, NB, padded_ident(cat_sizes[n_trunk - 1]));
+  } else {
+    // 16x16x32 engine: K-blocks e_o (2), e_d (2), e_x (4) in the slot order of embedN_16
+    const int NSB = W / 16, NKB = W / 32;
+    bl.add_bias16(fb32.data(), C0, NSB);
+    bl.layer_ob16(F32.data(), C0, EIN, NSB,
+                  {{2, [](int k) { return nsmlp::embedN_col16(k, 3, 10); }},
+                   {2, [](int k) { const int c = nsmlp::embedN_col16(k, 3, 10); return c < 0 ? -1 : E3 + c; }},
+                   {4, [](int k) { const int c = nsmlp::embedN_col16(k, 6, 10); return c < 0 ? -1 : 2 * E3 + c; }}});
+    for (int i = 1; i < n_trunk; ++i) {
+      bl.add_bias16(b[t0 + i], cat_sizes[i], NSB);
+      bl.layer_ob16(w[t0 + i], cat_sizes[i], cat_sizes[i - 1], NSB, {{NKB, padded_ident(cat_sizes[i - 1])}});
+    }
+    bl.add_bias16(b[t0 + n_trunk], 1, 1);
+    bl.layer_ob16(w[t0 + n_trunk], 1, cat_sizes[n_trunk - 1], 1, {{NKB, padded_ident(cat_sizes[n_trunk - 1])}});
+  }
 
   ns_weights* h = new ns_weights();
   std::memset(h, 0, sizeof(*h));
-  h->kind = NS_KIND_DEPTHNET; h->dtype = dtype; h->width = W; h->depth = n; h->skip = -1;
+  h->kind = NS_KIND_DEPTHNET; h->dtype = dtype; h->width = W; h->depth = n_trunk; h->skip = -1; h->layout = layout;
   int rc = finish(bl, h);
-  if (rc == NS_OK) {
-    // stash for two branch outputs per wave: kDepthnetMaxGrid workgroups x waves x 2 x NB blocks,
-    // one block = 64 lanes x (64 B fp32 | 32 B 16-bit); waves per workgroup: 4 (fp32) or 8
-    const size_t blk_bytes = (dtype == NS_DTYPE_F32 ? 64 : 32) * 64;
-    const size_t waves = dtype == NS_DTYPE_F32 ? 4 : 8;
-    h->scratch_bytes = static_cast<size_t>(kDepthnetMaxGrid) * waves * 2 * NB * blk_bytes;
-    hipError_t e = hipMalloc(&h->scratch_dev, h->scratch_bytes);
-    if (e != hipSuccess) { ns::set_error("ns_pack_depthnet: hipMalloc scratch -> %s", hipGetErrorString(e)); rc = NS_E_HIP; }
-  }
   if (rc != NS_OK) { ns_weights_destroy(h); return rc; }
   *out = h;
+  return NS_OK;
+}
+
+int ns_pack_depthnet(int n_layers, int width, const float* const* w, const float* const* b, int dtype,
+                     ns_weights** out) {
+  NS_REQUIRE(n_layers >= 1 && n_layers <= 64 && width >= 1, "bad shape");
+  std::vector<int> sizes(n_layers, width);
+  return ns_pack_depthnet_ex(n_layers, sizes.data(), n_layers, sizes.data(), w, b, dtype, out);
+}
+
+int ns_fold_depthnet_front(int n_branch, const int* hidden_sizes, int c0, const float* const* w, const float* const* b,
+                           float* F_out, float* bias_out) {
+  NS_REQUIRE(hidden_sizes && w && b && F_out && bias_out && n_branch >= 1 && c0 >= 1, "bad argument");
+  for (int i = 0; i < 3 * n_branch + 1; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
+  std::vector<float> F, fb;
+  fold_depthnet_front(n_branch, hidden_sizes, c0, w, b, F, fb);
+  std::memcpy(F_out, F.data(), F.size() * sizeof(float));
+  std::memcpy(bias_out, fb.data(), fb.size() * sizeof(float));
+  return NS_OK;
+}
+
+int ns_fold_nerf_views(int W, const float* w_feature, const float* b_feature, const float* w_views, const float* b_views,
+                       float* w_out, float* b_out) {
+  NS_REQUIRE(W >= 2 && w_feature && b_feature && w_views && b_views && w_out && b_out, "bad argument");
+  std::vector<float> wv, bv;
+  fold_nerf_views(W, w_feature, b_feature, w_views, b_views, wv, bv);
+  std::memcpy(w_out, wv.data(), wv.size() * sizeof(float));
+  std::memcpy(b_out, bv.data(), bv.size() * sizeof(float));
   return NS_OK;
 }
 
@@ -300,7 +464,6 @@ void ns_weights_destroy(ns_weights* w) {
   if (!w) return;
   if (w->stream_dev) (void)hipFree(w->stream_dev);
   if (w->bias_dev) (void)hipFree(w->bias_dev);
-  if (w->scratch_dev) (void)hipFree(w->scratch_dev);
   delete w;
 }
 

@@ -50,24 +50,34 @@ class DepthNet(nn.Module):
         return pts
 
     def _check_supported(self):
+        """The HIP kernels run the FOLDED network (ns_pack.hip): any skip-branch widths, trunk widths <= 256."""
+        if max(self.cat_hidden_sizes) > 256:
+            raise NotImplementedError(
+                f"the HIP kernels implement DepthNet trunks up to 256 wide (cat_hidden_sizes={self.cat_hidden_sizes})")
+        if self.multires != 10 or self.origin_dims != 63 or self.direction_dims != 63:
+            raise NotImplementedError("the HIP kernel is built for multires=10 and 3-channel origins/directions")
+
+    def _train_shape(self):
+        """(n_layers, width) for the layer-by-layer training path (autograd.DepthNetFunction), which keeps the literal,
+        un-folded chain and is written for one uniform width and as many trunk as branch layers (the production
+        shape, experiments/run.py:101-109)."""
+        self._check_supported()
         widths = set(self.hidden_sizes) | set(self.cat_hidden_sizes)
         if len(widths) != 1 or len(self.hidden_sizes) != len(self.cat_hidden_sizes):
             raise NotImplementedError(
-                "the HIP kernel implements DepthNet with one uniform hidden width and as many trunk as branch "
+                "the HIP training step implements DepthNet with one uniform hidden width and as many trunk as branch "
                 f"layers (hidden_sizes={self.hidden_sizes}, cat_hidden_sizes={self.cat_hidden_sizes})")
-        if self.multires != 10 or self.origin_dims != 63 or self.direction_dims != 63:
-            raise NotImplementedError("the HIP kernel is built for multires=10 and 3-channel origins/directions")
         return len(self.hidden_sizes), widths.pop()
 
     def packed(self, dtype: Optional[str] = None) -> ops.PackedWeights:
         name = dtype or ops.get_compute_dtype()
         if name not in self._packed:
-            n, width = self._check_supported()
+            self._check_supported()
             mods = (list(self.origin_layers) + list(self.direction_layers) + list(self.intersection_layers)
                     + [m for m in self.cat_layers if isinstance(m, nn.Linear)] + [self.to_depth[0]])
             dev = self.to_depth[0].weight.device
-            self._packed[name] = ops.pack_depthnet([m.weight for m in mods], [m.bias for m in mods], n, width, name,
-                                                   dev if dev.type == "cuda" else "cuda")
+            self._packed[name] = ops.pack_depthnet([m.weight for m in mods], [m.bias for m in mods], self.hidden_sizes,
+                                                   self.cat_hidden_sizes, name, dev if dev.type == "cuda" else "cuda")
         return self._packed[name]
 
     def repack(self):

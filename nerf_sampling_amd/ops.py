@@ -152,16 +152,24 @@ def pack_nerf(weights: Sequence[Tensor], biases: Sequence[Tensor], D: int, W: in
     return PackedWeights(out.value, "nerf", name, torch.device(device))
 
 
-def pack_depthnet(weights: Sequence[Tensor], biases: Sequence[Tensor], n_layers: int, width: int,
-                  dtype: Optional[str] = None, device="cuda") -> PackedWeights:
-    """order: origin_layers.*, direction_layers.*, intersection_layers.*, cat_layers.{0,2,..}, to_depth.0"""
+def pack_depthnet(weights: Sequence[Tensor], biases: Sequence[Tensor], hidden_sizes: Sequence[int],
+                  cat_hidden_sizes: Sequence[int], dtype: Optional[str] = None, device="cuda") -> PackedWeights:
+    """order: origin_layers.*, direction_layers.*, intersection_layers.*, cat_layers.{0,2,..}, to_depth.0
+
+    ``hidden_sizes``: the widths of the three skip branches (any); ``cat_hidden_sizes``: the trunk widths (each <= 256).
+    The affine branches are folded into the first trunk layer by the packer (ns_pack_depthnet_ex)."""
     lib = _lib.load()
+    hs = (C.c_int * len(hidden_sizes))(*[int(v) for v in hidden_sizes])
+    cs = (C.c_int * len(cat_hidden_sizes))(*[int(v) for v in cat_hidden_sizes])
+    if len(weights) != 3 * len(hidden_sizes) + len(cat_hidden_sizes) + 1 or len(biases) != len(weights):
+        raise ValueError("pack_depthnet: expected 3 * len(hidden_sizes) + len(cat_hidden_sizes) + 1 weight tensors")
     wa, k1 = _host_ptr_array(weights)
     ba, k2 = _host_ptr_array(biases)
     out = C.c_void_p()
     name = dtype or _compute_dtype
     with torch.cuda.device(device):
-        check(lib.ns_pack_depthnet(n_layers, width, wa, ba, dtype_code(name), C.byref(out)), "ns_pack_depthnet")
+        check(lib.ns_pack_depthnet_ex(len(hidden_sizes), hs, len(cat_hidden_sizes), cs, wa, ba, dtype_code(name),
+                                      C.byref(out)), "ns_pack_depthnet_ex")
     return PackedWeights(out.value, "depthnet", name, torch.device(device))
 
 
@@ -339,7 +347,8 @@ class RenderWorkspace:
         self.buf: Optional[Tensor] = None
 
     def get(self, nbytes: int, device) -> Tensor:
-        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+        # + 256: callers align the base pointer up to 256 bytes
+        if self.buf is None or self.buf.numel() < nbytes + 256 or self.buf.device != torch.device(device):
             self.buf = torch.empty((nbytes + 256,), dtype=torch.uint8, device=device)
         return self.buf
 
@@ -402,9 +411,11 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
     if extras:
         out["z"] = torch.empty((R, N), dtype=torch.float32, device=device)
-        out["weights"] = torch.empty((R, N), dtype=torch.float32, device=device)
+        # one sample: the reference's weights are [R, 0] (its dists are empty) and ns_raw2outputs writes none
+        out["weights"] = torch.empty((R, 0 if N == 1 else N), dtype=torch.float32, device=device)
         out["pts"] = torch.empty((R, N, 3), dtype=torch.float32, device=device)
-        a.z_dev, a.weights_dev, a.pts_dev = out["z"].data_ptr(), out["weights"].data_ptr(), out["pts"].data_ptr()
+        a.z_dev, a.pts_dev = out["z"].data_ptr(), out["pts"].data_ptr()
+        a.weights_dev = out["weights"].data_ptr() if N > 1 else None
     if mlp_events is not None:
         a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
     check(lib.ns_render_rays_depthnet(C.byref(a), _stream(device)), "ns_render_rays_depthnet")

@@ -158,13 +158,11 @@ class Trainer:
         if self.render_only:
             return self.render(self.render_test, self.save_scene_data, images, i_test, render_poses, hwf,
                                render_kwargs_test)
-        if self.use_batching:
-            raise NotImplementedError("use_batching (rays shuffled over all images) is not implemented; the "
-                                      "experiments run with no_batching: True (lego.yaml)")
-        poses = torch.tensor(np.asarray(poses)).to(dev)
+        images, poses, rays_rgb, i_batch = self.prepare_raybatch_tensor_if_batching_random_rays(poses, images, i_train)
         psnr = None
         for i in range(self.start + 1, N_iters):
-            _, _, batch_rays, target_s = self.sample_random_ray_batch(None, 0, i_train, images, poses, i)
+            rays_rgb, i_batch, batch_rays, target_s = self.sample_random_ray_batch(rays_rgb, i_batch, i_train, images,
+                                                                                   poses, i)
             loss, depth_net_loss, psnr, _ = self.core_optimization_loop(sampling_optimizer, render_kwargs_train,
                                                                          batch_rays, i, target_s)
             self.update_learning_rate(optimizer)
@@ -185,8 +183,39 @@ class Trainer:
         for param_group in optimizer.param_groups:
             param_group["lr"] = new_lrate
 
+    def prepare_raybatch_tensor_if_batching_random_rays(self, poses, images, i_train):
+        """(images, poses, rays_rgb, i_batch) -- Trainer.py:232-269.  With use_batching the rays of every TRAINING image
+        are generated once (ns_get_rays, on the device), joined with their pixel colours into rays_rgb
+        [(n_train H W), ro+rd+rgb, 3] and shuffled with numpy's generator: the reference calls np.random.shuffle on the
+        array itself, which draws the same permutation as shuffling an index vector of that length."""
+        dev = "cuda" if self.device == "cuda" else self.device
+        poses_t = torch.tensor(np.asarray(poses), dtype=torch.float32).to(dev)
+        if not self.use_batching:
+            return images, poses_t, None, None
+        rows = []
+        for img_i in i_train:
+            o, d, _ = ops.get_rays(self.H, self.W, self.K, poses_t[img_i, :3, :4], device=dev)
+            rgb = torch.tensor(np.asarray(images[img_i]), dtype=torch.float32, device=o.device).reshape(-1, 3)
+            rows.append(torch.stack([o, d, rgb[:, :3]], 1))            # [H*W, 3, 3]
+        rays_rgb = torch.cat(rows, 0)
+        perm = np.arange(rays_rgb.shape[0])
+        np.random.shuffle(perm)
+        rays_rgb = rays_rgb[torch.from_numpy(perm).to(rays_rgb.device)]
+        images = torch.tensor(np.asarray(images), dtype=torch.float32).to(dev)
+        return images, poses_t, rays_rgb, 0
+
     def sample_random_ray_batch(self, rays_rgb, i_batch, i_train, images, poses, i):
-        """N_rand random pixels of one random training image (the no_batching branch of Trainer.py:400-475)."""
+        """use_batching: the next N_rand rows of the shuffled rays_rgb, reshuffled (torch.randperm, as the reference)
+        after an epoch; otherwise N_rand random pixels of one random training image -- Trainer.py:400-475."""
+        if self.use_batching:
+            batch = torch.transpose(rays_rgb[i_batch : i_batch + self.N_rand], 0, 1)     # [ro+rd+rgb, B, 3]
+            batch_rays, target_s = batch[:2], batch[2]
+            i_batch += self.N_rand
+            if i_batch >= rays_rgb.shape[0]:
+                print("Shuffle data after an epoch!")
+                rays_rgb = rays_rgb[torch.randperm(rays_rgb.shape[0], device=rays_rgb.device)]
+                i_batch = 0
+            return rays_rgb, i_batch, batch_rays, target_s
         img_i = 42 if self.single_image else np.random.choice(i_train)
         target = torch.tensor(np.asarray(images[img_i]), dtype=torch.float32)
         pose = poses[img_i, :3, :4]
@@ -287,6 +316,17 @@ class DepthNetTrainer(BlenderTrainer):
             kw["depth_network"] = depth_network
             kw["model_mode"] = mode
         return optimizer, sampling_optimizer, render_kwargs_train, render_kwargs_test
+
+    def save_rays_data(self, rays_o, pts, alpha):
+        """{basedir}/{expname}/{expname}_{global_step}.safetensors holding origins / pts / alpha, the dump
+        experiments/plot.py reads for its point-cloud plots (sampling_trainer.py:124-138)."""
+        from safetensors.torch import save_file
+
+        os.makedirs(os.path.join(self.basedir, self.expname), exist_ok=True)
+        filename = os.path.join(self.basedir, self.expname, f"{self.expname}_{self.global_step}.safetensors")
+        save_file({"origins": rays_o.detach().contiguous(), "pts": pts.detach().contiguous(),
+                   "alpha": alpha.detach().contiguous()}, filename)
+        return filename
 
     def raw2outputs(self, raw, z_vals, rays_d, raw_noise_std=0, white_bkgd=True, pytest=False, **kwargs):
         """7-tuple (rgb_map, disp_map, acc_map, depth_map, density, alphas, weights).

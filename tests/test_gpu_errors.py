@@ -19,7 +19,10 @@ def test_unsupported_network_shapes_raise():
     from nerf_sampling_amd.depth_net import DepthNet
     from nerf_sampling_amd.run_nerf_helpers import NeRF
 
-    dn = DepthNet().cuda()        # class defaults: cat sizes [128,128,128,128,256] -- not a uniform width
+    dn = DepthNet(hidden_sizes=[64, 64], cat_hidden_sizes=[128, 512]).cuda()    # a trunk layer wider than 256
+    with pytest.raises(NotImplementedError):
+        dn(torch.zeros(4, 3).cuda(), torch.ones(4, 3).cuda())
+    dn = DepthNet(hidden_sizes=[64, 64], cat_hidden_sizes=[128, 128], multires=6).cuda()   # not the multires the kernel embeds
     with pytest.raises(NotImplementedError):
         dn(torch.zeros(4, 3).cuda(), torch.ones(4, 3).cuda())
     net = NeRF(D=8, W=96, input_ch=63, input_ch_views=27, use_viewdirs=True).cuda()   # width without a kernel
@@ -77,6 +80,7 @@ def test_empty_and_degenerate_inputs(gpu_modules):
                                          torch.tensor([[0.0, 0.0, -1.0]]).cuda()), n_samples=1, mode="depth_only", std=0.1,
                                    extras=True)
     assert one["rgb"].shape == (1, 3) and one["z"].shape == (1, 1) and torch.isfinite(one["rgb"]).all()
+    assert one["weights"].shape == (1, 0)       # the reference's weights for one sample are [R, 0], never uninitialised
 
 
 def test_gaussian_mode_through_the_operator_api(gpu_modules):

@@ -261,12 +261,13 @@ def test_nerf_mlp_f32(ops, gpu_modules, golden, scene):
 
 
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
-@pytest.mark.parametrize("dtype,tol", [("bf16", 4e-2), ("f16", 6e-3)])
+@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("f16", 4.5e-3)])     # measured rms/scale ~1e-2 / 1.5e-3 (sigma channel)
 def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
     """16-bit operands, fp32 accumulation: error is operand rounding (2^-9 bf16, 2^-12 fp16) through ~10 layers."""
     for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, dtype).items():
         scale = np.abs(exp).max(axis=(0, 1))
         rms = np.sqrt(((mine - exp) ** 2).mean(axis=(0, 1))) / scale
+        print(f"nerf_mlp_16bit {scene} {which} {dtype}: rms/scale {rms}")
         assert (rms < tol).all(), (which, dtype, rms)
 
 
@@ -294,6 +295,7 @@ def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
             got = ops.nerf_forward(net.packed(dtype), pts, view).cpu().numpy()
             assert got.shape == (R, N, 4) and np.isfinite(got).all()
             err = np.abs(got - ref).reshape(-1, 4).max(0) / scale
+            print(f"shapes D{D} W{W} skip{skip} R{R} N{N} {dtype}: max err/scale {err.max():.3e}")
             assert (err < tol).all(), (D, W, skip, R, N, dtype, err)
 
 
@@ -341,7 +343,7 @@ def test_depthnet_f32(ops, gpu_modules, golden, scene):
 
 
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
-@pytest.mark.parametrize("dtype,tol", [("bf16", 0.15), ("f16", 0.03)])
+@pytest.mark.parametrize("dtype,tol", [("bf16", 1.0e-2), ("f16", 1.3e-3)])   # measured rms 2.5-3.3e-3 / 3.2-4.2e-4 (z in [2,6])
 def test_depthnet_16bit(ops, gpu_modules, golden, scene, dtype, tol):
     g = golden("depthnet")
     z = ops.depthnet_forward(gpu_modules(scene)["depth"].packed(dtype), dev(g["o"]), dev(g["d"]))
@@ -359,3 +361,34 @@ def test_depthnet_ragged_sizes(ops, gpu_modules):
         d = -o / 4.0 + 0.1 * torch.randn(R, 3, generator=gen)
         exp = O.depthnet_forward(m["params"]["depth"], o, d)
         close(m["depth"](o.cuda(), d.cuda()), exp, 0, 2e-4)
+
+
+@pytest.mark.parametrize("hidden,cat", [([128] * 6, [128, 128, 128, 128, 256]),      # the reference's class defaults
+                                        ([48, 80], [64, 16, 200, 256]), ([32], [96]), ([256] * 3, [256] * 4)])
+def test_depthnet_shapes_vs_oracle(ops, hidden, cat):
+    """DepthNet shapes other than one uniform width -- the reference's class defaults (depth_net.py:13-16, pinned by its
+    own structure tests, tests.py:115-194), ragged widths, one layer -- through the folded kernels, all three operand
+    types, against the oracle's literal chain on the module's own (torch-default-init, seeded) weights."""
+    from nerf_sampling_amd.depth_net import DepthNet
+
+    torch.manual_seed(31 + len(hidden) + sum(cat))
+    dn = DepthNet(hidden_sizes=hidden, cat_hidden_sizes=cat)
+    # default init shrinks the signal layer by layer (z would be a constant); the synthetic scenes' gains keep it alive
+    p = {k: v.detach().clone() * (2.4 if "cat_layers" in k and k.endswith("weight") else 1.7 if k.endswith("weight") else 1.0)
+         for k, v in dn.state_dict().items()}
+    dn.load_state_dict(p)
+    dn = dn.cuda()
+    for q in dn.parameters():
+        q.requires_grad_(False)
+    gen = torch.Generator().manual_seed(5)
+    for R in (1, 70, 300):
+        o = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1) * 4.0
+        d = -o / 4.0 + 0.1 * torch.randn(R, 3, generator=gen)
+        exp = O.depthnet_forward(p, o, d)
+        assert exp.shape == (R, 1)
+        if R == 300:
+            assert float(exp.std()) > 0.05                  # the depth really varies across rays
+        close(ops.depthnet_forward(dn.packed("f32"), o.cuda(), d.cuda()), exp, 0, 2e-4)
+        for dtype, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+            z = ops.depthnet_forward(dn.packed(dtype), o.cuda(), d.cuda())
+            assert float((z.cpu() - exp).abs().max()) < tol, (dtype, R, float((z.cpu() - exp).abs().max()))

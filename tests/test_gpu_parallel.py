@@ -55,3 +55,23 @@ def test_two_ranks_assemble_the_single_process_frame(tmp_path, gpu_modules):
             got = np.load(os.path.join(str(tmp_path), f"r{r}_f{k}.npz"))
             np.testing.assert_array_equal(got["rgb"].reshape(-1, 3), full["rgb"].cpu().numpy())   # bit exact
             np.testing.assert_array_equal(got["disp"].reshape(-1), full["disp"].cpu().numpy())
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no outer launcher (how the round-end driver may run it) starts two rank processes
+    itself and labels the line with the world size it really ran on (gloo here: both ranks share the one GPU)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["backend"] == "gloo"
+    assert out["value"] > 0 and out["steps"] == 2 and out["scaling"] == "strong"

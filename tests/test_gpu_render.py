@@ -8,6 +8,8 @@ perturbation of sigma the size of fp32 GEMM rounding noise (the last sample's al
 1 - exp(-relu(sigma) * 1e10), a step function of sigma's sign); those rays are counted and must be rare.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -275,15 +277,109 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     assert torch.equal(lean["rgb"], ref["rgb"]) and torch.equal(lean["disp"], ref["disp"])
 
 
-@pytest.mark.parametrize("dtype,min_psnr", [("bf16", 18.0), ("f16", 25.0)])
-def test_full_size_frame_properties(gpu_modules, dtype, min_psnr):
-    """BASELINE config 2 size (800x800, DepthNet + 64 samples/ray): size-independent properties of the
-    16-bit MFMA path, and PSNR against the fp32 path of the same build on a 200-row band.
+# Measured on MI355X (tools/frame16_diag.py, profiles/r02_frame16_diag.log): rms error of the HIP sigma against the
+# oracle's at the same points, as a fraction of max |sigma| of the band.  bench.py uses the same constants for its mask.
+SIGMA_NOISE_FRAC = {"bf16": 1.55e-2, "f16": 2.4e-3}
 
-    The PSNR floor is low on purpose: the reference composites the last sample with dist = 1e10, so a
-    ray's colour is a step function of the sign of its last sigma, and on the synthetic scene ~5-15 % of
-    rays have |sigma_last| inside the 16-bit operand noise.  Median error and the raw-level tests in
-    test_gpu_kernels.py are the meaningful 16-bit accuracy statements."""
+
+def conditioning_mask(raw_ref, z_ref, d, rgb_ref, sigma_eps, tol=1e-2):
+    """Rays whose ORACLE colour moves by more than `tol` when every sigma moves by +-sigma_eps: the reference composites
+    the last sample with dist = 1e10 (sampling_trainer.py:176-180), so alpha_last = step(sigma_last) and a ray's colour
+    is discontinuous in sigma_last wherever transmittance is left (the same mask as test_frame_config1_fp32_gate)."""
+    ill = torch.zeros(raw_ref.shape[0], dtype=torch.bool)
+    for sgn in (-1.0, 1.0):
+        pert = raw_ref.clone()
+        pert[..., 3] += sgn * sigma_eps
+        ill |= (O.raw2outputs(pert, z_ref, d, 0.0, True)[0] - rgb_ref).abs().max(-1).values > tol
+    return ill
+
+
+def _psnr(a, b):
+    mse = float(((a - b) ** 2).mean())
+    return float("inf") if mse == 0 else -10 * np.log10(mse)
+
+
+@pytest.fixture(scope="module")
+def oracle_band():
+    """BASELINE configs[1] shape: a 50-row band of an 800x800 frame, DepthNet + 64 samples/ray, rendered by the oracle."""
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    p = O.make_scene("lego_synth")
+    H = W = 800
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(30.0, -30.0, 4.0)[:3, :4]
+    r0, rows = 375, 50
+    batch, o, d, _ = O.ray_batch_from_camera(H, W, K, c2w, 2.0, 6.0)
+    sl = slice(r0 * W, (r0 + rows) * W)
+    batch, o, d = batch[sl], o[sl], d[sl]
+    with torch.no_grad():
+        z_mean = O.depthnet_forward(p["depth"], o, d)
+        pts, z = O.place_samples(o, d, z_mean, 64, "uniform", 0.1)
+        raw = O.run_network(p["fine"], pts, batch[:, -3:])
+        rgb = O.raw2outputs(raw, z, d, 0.0, True)[0]
+    return dict(p=p, H=H, W=W, K=K, c2w=c2w, r0=r0, rows=rows, o=o, d=d, view=batch[:, -3:], z_mean=z_mean, z=z, raw=raw,
+                rgb=rgb)
+
+
+#                                  z rms   sigma/max  ill frac  PSNR well  PSNR with oracle sigma_last   (gates <= ~3x measured)
+@pytest.mark.parametrize("dtype,g_z,g_sig,g_ill,g_psnr,g_fix", [("bf16", 1.0e-2, 4.0e-2, 0.15, 58.0, 47.0),
+                                                               ("f16", 1.4e-3, 7.0e-3, 0.04, 68.0, 54.0)])
+def test_frame16_vs_oracle(gpu_modules, oracle_band, dtype, g_z, g_sig, g_ill, g_psnr, g_fix):
+    """The headline 16-bit path against the ORACLE at image level, on the configs[1] shape.
+
+    Measured (MI355X, round 2): bf16 / f16  z rms 3.3e-3 / 4.6e-4;  sigma noise 1.54e-2 / 2.4e-3 of max |sigma|;
+    PSNR(build || oracle) over ALL rays 24.2 / 31.3 dB, over the well-conditioned rays 68.7 / 79.7 dB with 11.5 % / 2.5 %
+    of rays ill-conditioned at 3x the measured sigma noise; every ray that differs by > 1e-2 is inside the mask; and
+    compositing the HIP raw with the ORACLE's sigma_last alone restores 52.5 / 60.1 dB over all rays -- i.e. the
+    all-ray PSNR is the last-sample step rule (alpha_last = step(sigma_last)), not an accuracy problem of the kernels."""
+    from nerf_sampling_amd import ops
+
+    b = oracle_band
+    m = gpu_modules("lego_synth")
+    dn, nf = m["depth"].packed(dtype), m["fine"].packed(dtype)
+    oc, dc, vc = b["o"].cuda(), b["d"].cuda(), b["view"].cuda()
+    # stage errors at identical inputs
+    z_mean = ops.depthnet_forward(dn, oc, dc)
+    z_rms = float((z_mean.cpu() - b["z_mean"]).pow(2).mean().sqrt())
+    _, zz = ops.place_samples(oc, dc, z_mean, 64, "uniform", 0.1)
+    raw = ops.nerf_forward_rays(nf, oc, dc, zz, vc).cpu()
+    with torch.no_grad():
+        pts_o, _ = O.place_samples(b["o"], b["d"], z_mean.cpu(), 64, "uniform", 0.1)
+        raw_o = O.run_network(b["p"]["fine"], pts_o, b["view"])          # the oracle's MLP at the HIP path's own points
+        rgb_o_given_z = O.raw2outputs(raw_o, zz.cpu(), b["d"], 0.0, True)[0]
+    sig_max = float(b["raw"][..., 3].abs().max())
+    sig_frac = float((raw[..., 3] - raw_o[..., 3]).pow(2).mean().sqrt()) / sig_max
+    logit_rms = float((raw[..., :3] - raw_o[..., :3]).pow(2).mean().sqrt())
+    # the frame itself: the one-call fused path on camera rays (what bench.py times)
+    out = ops.render_rays_depthnet(dn, nf, camera=(b["H"], b["W"], b["K"], b["c2w"], b["r0"], b["r0"] + b["rows"]),
+                                   n_samples=64, mode="uniform", std=0.1)
+    rgb = out["rgb"].cpu()
+    err = (rgb - b["rgb"]).abs().max(-1).values
+    ill = conditioning_mask(b["raw"], b["z"], b["d"], b["rgb"], 3.0 * SIGMA_NOISE_FRAC[dtype] * sig_max)
+    well = ~ill
+    psnr_all, psnr_well = _psnr(rgb, b["rgb"]), _psnr(rgb[well], b["rgb"][well])
+    big = err > 1e-2
+    # the last-sample rule in isolation: HIP raw, oracle's sigma_last
+    raw_fix = raw.clone()
+    raw_fix[:, -1, 3] = raw_o[:, -1, 3]
+    with torch.no_grad():
+        rgb_fix = O.raw2outputs(raw_fix, zz.cpu(), b["d"], 0.0, True)[0]
+    psnr_fix = _psnr(rgb_fix, rgb_o_given_z)
+    print(f"{dtype}: z rms {z_rms:.2e}; sigma noise {sig_frac:.2e} of max|sigma| ({sig_max:.1f}); rgb-logit rms {logit_rms:.2e}; "
+          f"PSNR all {psnr_all:.2f} dB, well-conditioned {psnr_well:.2f} dB (max err {float(err[well].max()):.2e}); "
+          f"ill {float(ill.float().mean()):.4f}; err>1e-2: {float(big.float().mean()):.4f} of rays, "
+          f"{float((big & well).float().mean()):.5f} outside the mask; with oracle sigma_last {psnr_fix:.2f} dB")
+    assert z_rms < g_z
+    assert sig_frac < g_sig and abs(sig_frac / SIGMA_NOISE_FRAC[dtype] - 1.0) < 0.3     # the mask's noise level is the measured one
+    assert float(ill.float().mean()) < g_ill
+    assert psnr_well > g_psnr and float(err[well].max()) < 2e-2
+    assert float((big & well).float().mean()) < 2e-4          # every visibly different ray is an ill-conditioned one
+    assert psnr_fix > g_fix                                    # ... and the step rule at the last sample is what differs
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_full_size_frame_properties(gpu_modules, dtype):
+    """BASELINE config 2 size (800x800, DepthNet + 64 samples/ray): size-independent properties of the
+    16-bit MFMA path (accuracy against the oracle: test_frame16_vs_oracle above)."""
     from nerf_sampling_amd import ops
 
     m = gpu_modules("lego_synth")
@@ -303,12 +399,8 @@ def test_full_size_frame_properties(gpu_modules, dtype, min_psnr):
     assert torch.equal(lo["rgb"], rgb[band[0] * W : band[1] * W])               # shard == slice of the frame
     ref = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
                                    camera=(H, W, K, c2w, band[0], band[1]), n_samples=64, mode="uniform", std=0.1)
-    mse = float(((lo["rgb"] - ref["rgb"]) ** 2).mean())
-    psnr = -10 * np.log10(max(mse, 1e-20))
     med = float((lo["rgb"] - ref["rgb"]).abs().max(-1).values.median())
-    print(f"{dtype}: PSNR vs fp32 path on rows {band} = {psnr:.2f} dB, median |rgb err| = {med:.2e}")
-    assert psnr > min_psnr
-    assert med < (2e-3 if dtype == "bf16" else 3e-4)
+    assert med < (1e-3 if dtype == "bf16" else 1.5e-4)
 
 
 def test_fused_hierarchical_matches_operator_chain(golden, gpu_modules):

@@ -72,3 +72,16 @@ def test_two_rank_frame_equals_single_process(tmp_path, H, W, world):
         assert got["rgb"].shape == (H, W, 3) and got["disp"].shape == (H, W)
         np.testing.assert_allclose(got["rgb"].reshape(-1, 3), rgb.numpy(), rtol=0, atol=2e-5)  # CPU GEMM rounding depends on the batch split
         np.testing.assert_allclose(got["disp"].reshape(-1), disp.numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """bench.py --gpus N under a launcher that made a different world size exits non-zero instead of printing a
+    mislabelled number (checked before anything touches a GPU, so this runs on the CPU box)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not r.stdout.strip()
