@@ -36,6 +36,9 @@ extern "C" {
 #define NS_DTYPE_F32 0  /* v_mfma_f32_32x32x2_f32, exact-fp32 parity path (k-major engine)             */
 #define NS_DTYPE_BF16 1 /* v_mfma_f32_16x16x32_bf16, both networks (output-sub-block-major engine)      */
 #define NS_DTYPE_F16 2  /* v_mfma_f32_16x16x32_f16, same engine                                         */
+#define NS_DTYPE_F16X3 3 /* split fp16 operands (x = hi + lo), three v_mfma_f32_16x16x32_f16 per product term: fp32-grade
+                          * results (the fp32 parity gates hold) at ~1/3 of the fp16 rate; operands must fit fp16's
+                          * range (|w| < 65504, checked at pack time)                                    */
 
 /* sample placement modes, utils.py:220-244 */
 #define NS_MODE_DEPTH_ONLY 0

@@ -2,8 +2,8 @@
 // ns_mlp_engine.h -- the same engine as the radiance-field kernel (ns_nerf_mlp_ob16.hip).  After the pack-time fold
 // (ns_pack.hip: the three affine skip branches and the first trunk layer are ONE 252 -> W layer) the network is a
 // plain MLP:  cat[gamma(o), gamma(d), gamma(sphere intersections)] (8 K-blocks) -> W, LeakyReLU -> ... -> 1, sigmoid.
-// A wave owns T = 4 tiles of 16 rays; activations never leave the register file; no global scratch, no spills.
-// HBM traffic per ray: 24 B in, 4 B out.
+// A wave owns T = 4 tiles of 16 rays (T = 2 with split "f16x3" operands, the fp32-grade path on the same engine);
+// activations never leave the register file; no global scratch, no spills.  HBM traffic per ray: 24 B in, 4 B out.
 #include "ns_common.h"
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
@@ -12,9 +12,34 @@ namespace {
 
 using namespace nsmlp;
 
-constexpr int kT = 4;        // 16-ray tiles per wave
 constexpr int kWaves = 4;    // one wave per SIMD
 constexpr int kInKB = 8;     // K-blocks of the folded input layer: e_o (2), e_d (2), e_x (4)
+
+// Engine policies: plain 16-bit operands (T = 4 tiles of 16 rays per wave) or split fp16 operands ("f16x3", T = 2:
+// every activation block is a hi/lo pair, so half the tiles fit the register file).
+template <class M_>
+struct Plain16 {
+  using M = M_;
+  static constexpr int T = 4;
+  static constexpr bool kPreciseTrig = false;
+  template <int NSB, int NKB, int ACT, class PipeT, class OutT, class InF>
+  __device__ static __forceinline__ void layer(PipeT& pipe, const float* bias, int g, OutT& out, f32x4a (&last)[T], InF&& in) {
+    layer_ob16<M, T, NSB, NKB, ACT>(pipe, bias, g, out, last, static_cast<InF&&>(in));
+  }
+  template <int ACT, int NSB, class OutT>
+  __device__ static __forceinline__ void convert_last(OutT& out, const f32x4a (&last)[T]) { convert_last16<M, ACT, T, NSB>(out, last); }
+};
+struct Split16 {
+  using M = Mma16F16x3;
+  static constexpr int T = 2;
+  static constexpr bool kPreciseTrig = true;     // the polynomial sine of the fp32 path (v_sin_f32 is ~1e-6, too coarse here)
+  template <int NSB, int NKB, int ACT, class PipeT, class OutT, class InF>
+  __device__ static __forceinline__ void layer(PipeT& pipe, const float* bias, int g, OutT& out, f32x4a (&last)[T], InF&& in) {
+    layer_ob16x3<T, NSB, NKB, ACT>(pipe, bias, g, out, last, static_cast<InF&&>(in));
+  }
+  template <int ACT, int NSB, class OutT>
+  __device__ static __forceinline__ void convert_last(OutT& out, const f32x4a (&last)[T]) { convert_last16x3<ACT, T, NSB>(out, last); }
+};
 
 struct Depth16Args {
   const char* stream;
@@ -29,11 +54,13 @@ struct Depth16Args {
   float* z;
 };
 
-template <class M, int NKB>   // NKB = W / 32 K-blocks of a hidden layer
+template <class E, int NKB>   // E: engine policy; NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
 depthnet_ob16_kernel(Depth16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int T = kT, NWAVES = kWaves, NSB = 2 * NKB;
+  using M = typename E::M;
+  constexpr int T = E::T, NWAVES = kWaves, NSB = 2 * NKB;
+  constexpr bool PT = E::kPreciseTrig;
   using Block = typename M::Block;
   using PipeT = Pipe<M, NWAVES, 0, kOb16Depth, kOb16Ahead>;
   const int lane = threadIdx.x & 63;
@@ -60,10 +87,10 @@ depthnet_ob16_kernel(Depth16Args a) {
   };
   // the NEXT group's rays are fetched by LDS-DMA right after layer 0 of the current one (no register is held across
   // the network, no global-load wait -- which would also wait for the weight DMA in flight -- at a group boundary):
-  // lane j fetches the six values of the j-th of the wave's 64 consecutive rays; slots o 0..2, d 3..5
+  // lane j fetches the six values of the j-th of the wave's 16 T consecutive rays; slots o 0..2, d 3..5
   auto prefetch = [&](int64_t grp) {
     bool valid;
-    const int64_t r = ray_of(grp, lane >> 4, lane & 15, valid);
+    const int64_t r = ray_of(grp, (lane >> 4) % T, lane & 15, valid);   // (T < 4: the upper lanes re-fetch, harmlessly)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       lds_dma4(a.o + r * 3 + c, stage_base + c * 256);
@@ -98,11 +125,11 @@ depthnet_ob16_kernel(Depth16Args a) {
         for (int c3 = 0; c3 < 3; ++c3) { x6[c3] = o[c3] + t0 * d[c3]; x6[3 + c3] = o[c3] + t1 * d[c3]; }
       }
       Block e3[2], e6[4];
-      embedN_16<M, false, 3, 10, 2>(e3, o, g);
+      embedN_16<M, PT, 3, 10, 2>(e3, o, g);
       e[t][0] = e3[0]; e[t][1] = e3[1];
-      embedN_16<M, false, 3, 10, 2>(e3, d, g);
+      embedN_16<M, PT, 3, 10, 2>(e3, d, g);
       e[t][2] = e3[0]; e[t][3] = e3[1];
-      embedN_16<M, false, 6, 10, 4>(e6, x6, g);
+      embedN_16<M, PT, 6, 10, 4>(e6, x6, g);
       e[t][4] = e6[0]; e[t][5] = e6[1]; e[t][6] = e6[2]; e[t][7] = e6[3];
     });
 
@@ -114,23 +141,23 @@ depthnet_ob16_kernel(Depth16Args a) {
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
 
     // layer 0 (folded): e -> hA
-    layer_ob16<M, T, NSB, kInKB, kLeaky>(ring, bias, g, hA, last, in_e);
-    convert_last16<M, kLeaky, T, NSB>(hA, last); bias += NSB * 16;
+    E::template layer<NSB, kInKB, kLeaky>(ring, bias, g, hA, last, in_e);
+    E::template convert_last<kLeaky, NSB>(hA, last); bias += NSB * 16;
     prefetch(grp + gridDim.x);   // clamped to the last ray past the end: loaded, never used
     int l = 1;
     for (; l + 1 < a.n_layers; l += 2) {   // two trunk layers per trip: hA -> hB -> hA
-      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
-      convert_last16<M, kLeaky, T, NSB>(hB, last); bias += NSB * 16;
-      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hA, last, in_B);
-      convert_last16<M, kLeaky, T, NSB>(hA, last); bias += NSB * 16;
+      E::template layer<NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
+      E::template convert_last<kLeaky, NSB>(hB, last); bias += NSB * 16;
+      E::template layer<NSB, NKB, kLeaky>(ring, bias, g, hA, last, in_B);
+      E::template convert_last<kLeaky, NSB>(hA, last); bias += NSB * 16;
     }
     if (l < a.n_layers) {  // odd layer left over: hA -> hB, then move back
-      layer_ob16<M, T, NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
-      convert_last16<M, kLeaky, T, NSB>(hB, last); bias += NSB * 16;
+      E::template layer<NSB, NKB, kLeaky>(ring, bias, g, hB, last, in_A);
+      E::template convert_last<kLeaky, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
     }
     // head (W -> 1): row 0 of a 16-row sub-block (lane group 0, register 0), sigmoid, z = near (1 - s) + far s
-    layer_ob16<M, T, 1, NKB, kNone>(ring, bias, g, hB, last, in_A);
+    E::template layer<1, NKB, kNone>(ring, bias, g, hB, last, in_A);
     if (g == 0) {
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
@@ -144,23 +171,25 @@ depthnet_ob16_kernel(Depth16Args a) {
   ring.finish();
 }
 
-int depth16_program_slabs(int W, int n_layers) {
+int depth16_program_slabs(int W, int n_layers, int cpk) {   // cpk: stream chunks per K-block (2 for split operands)
   const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
-  return ob16_layer_slabs(NSB, kInKB, dp) + (n_layers - 1) * ob16_layer_slabs(NSB, NKB, dp) + ob16_layer_slabs(1, NKB, dp);
+  return ob16_layer_slabs(NSB, cpk * kInKB, dp) + (n_layers - 1) * ob16_layer_slabs(NSB, cpk * NKB, dp) +
+         ob16_layer_slabs(1, cpk * NKB, dp);
 }
 
-template <class M, int NKB>
+template <class E, int NKB>
 int launch(Depth16Args& a, hipStream_t stream) {
+  using M = typename E::M;
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * 6 * 256;
   if (lds > 160 * 1024) {
     ns::set_error("ns_depthnet_forward: %zu bytes of LDS needed (too many layers for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
   }
-  auto kern = depthnet_ob16_kernel<M, NKB>;
+  auto kern = depthnet_ob16_kernel<E, NKB>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.R + 15) / 16;
-  const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
+  const int64_t n_groups = (n_tiles + kWaves * E::T - 1) / (kWaves * E::T);
   int cus = ns::cu_count();
   if (cus <= 0) cus = 256;
   const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
@@ -174,9 +203,10 @@ int launch(Depth16Args& a, hipStream_t stream) {
 // called by ns_depthnet_forward for handles packed with layout 16 (arguments validated there)
 int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const float* d_dev, int64_t R, float near_,
                              float far_, float sphere_radius, float* z_dev, hipStream_t stream) {
-  if (depth16_program_slabs(net->width, net->depth) != static_cast<int>(net->n_slabs)) {
+  const int cpk = net->dtype == NS_DTYPE_F16X3 ? 2 : 1;
+  if (depth16_program_slabs(net->width, net->depth, cpk) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_depthnet_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
-                  depth16_program_slabs(net->width, net->depth));
+                  depth16_program_slabs(net->width, net->depth, cpk));
     return NS_E_INVALID;
   }
   Depth16Args a{};
@@ -185,7 +215,8 @@ int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const fl
   a.n_layers = net->depth; a.o = o_dev; a.d = d_dev; a.R = R;
   a.near_ = near_; a.far_ = far_; a.radius = sphere_radius; a.z = z_dev;
   const bool wide = net->width == 256;
-  if (net->dtype == NS_DTYPE_BF16) return wide ? launch<Mma16BF16, 8>(a, stream) : launch<Mma16BF16, 4>(a, stream);
-  if (net->dtype == NS_DTYPE_F16) return wide ? launch<Mma16F16, 8>(a, stream) : launch<Mma16F16, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_BF16) return wide ? launch<Plain16<Mma16BF16>, 8>(a, stream) : launch<Plain16<Mma16BF16>, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_F16) return wide ? launch<Plain16<Mma16F16>, 8>(a, stream) : launch<Plain16<Mma16F16>, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_F16X3) return wide ? launch<Split16, 8>(a, stream) : launch<Split16, 4>(a, stream);
   return NS_E_UNSUPPORTED;
 }

@@ -34,6 +34,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef NS_OB16_DMA_SPREAD
+#define NS_OB16_DMA_SPREAD 0   // 1: a wave's four DMA pieces of a slab are issued a quarter slab apart instead of all after the barrier
+#endif
+#ifndef NS_OB16_BIAS_C
+#define NS_OB16_BIAS_C 0       // 1: the bias is the C operand of a sub-block's first MFMA (no per-tile copies into the accumulators)
+#endif
+
 constexpr int kChunkBytes = 1024;
 #ifndef NS_SLAB_CHUNKS
 #define NS_SLAB_CHUNKS 16
@@ -204,6 +211,9 @@ struct Pipe {
   uint32_t cur;         // this lane's LDS byte address in the open slab (chunk c at +c*1024)
   uint32_t nxt;         // ... and in the following one
   AFrag f[DEPTH];       // fragments of the next DEPTH chunks
+#ifdef NS_EXP_NODMA
+  bool exp_no_dma = false;
+#endif
 
   // One slab: LPW LDS-DMA instructions per wave.  They are issued through inline asm on purpose: with the
   // __builtin_amdgcn_global_load_lds form the compiler's waitcnt pass sees an LDS store it cannot disambiguate and
@@ -215,10 +225,44 @@ struct Pipe {
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
     const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+#ifdef NS_EXP_NODMA        // timing ablation: the ring is refilled by the prologue only (results are wrong)
+    if (exp_no_dma) {
+      asm volatile("" ::"v"(src + lane_off), "s"(dst));
+    } else {
+#pragma unroll
+      for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
+#endif
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
+  }
+
+  // the same slab, one DMA instruction at a time (spread over the chunk steps of the open slab by stream_chunks<> when
+  // NS_OB16_DMA_SPREAD: the four waves' sixteen 1-KiB pieces then do not queue behind each other in the CU's memory
+  // pipeline right after the barrier); issue_advance() closes the slab
+  template <int I>
+  __device__ __forceinline__ void issue_piece() {
+    static_assert(I >= 0 && I < LPW, "piece index");
+    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
+    const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    lds_dma16(src + I * NWAVES * kChunkBytes + lane_off, dst + I * NWAVES * kChunkBytes);
+  }
+  __device__ __forceinline__ void issue_advance() {
+    issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
+    issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
+  }
+  // begin_slab() without the refill: the caller issues the LPW pieces itself and then issue_advance()
+  __device__ __forceinline__ void begin_slab_no_issue() {
+    wait_vm<(AHEAD - 2) * LPW>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    cur = lds_off + read_slot * kSlabBytes + lane * 16;
+    read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
+    nxt = lds_off + read_slot * kSlabBytes + lane * 16;
   }
 
   // s_waitcnt vmcnt(N) alone (the other counters at "don't wait")
@@ -233,7 +277,11 @@ struct Pipe {
   // lgkmcnt(0) every fourth MFMA -- same kernel time (35.4 vs 35.2 ms), so the compiler-visible form stays.
   template <int OFF>
   __device__ __forceinline__ void load(AFrag& dst, uint32_t addr) const {
+#ifdef NS_EXP_NOLDS        // timing ablation: fragments are never re-read (results are wrong)
+    (void)dst; (void)addr;
+#else
     dst = *reinterpret_cast<const AFrag __attribute__((address_space(3)))*>(static_cast<uintptr_t>(addr + OFF));
+#endif
   }
   __device__ static __forceinline__ void wait_frag(AFrag&) {}
 
@@ -242,6 +290,9 @@ struct Pipe {
     issue_slab = 0; issue_slot = 0; read_slot = 0;
     lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
     static_for<AHEAD>([&](auto) { issue(); });    // slabs 0 .. AHEAD-1
+#ifdef NS_EXP_NODMA
+    exp_no_dma = true;
+#endif
     wait_vm<(AHEAD - 1) * LPW>();                 // my pieces of slab 0 have landed ...
     __builtin_amdgcn_s_barrier();                 // ... and everyone else's
     asm volatile("" ::: "memory");
@@ -373,9 +424,18 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
     constexpr int s = decltype(s_)::value;
     constexpr int USED = (TOTAL - s * kSlabChunks) < kSlabChunks ? (TOTAL - s * kSlabChunks) : kSlabChunks;
     static_assert(USED % PipeT::kDepth == 0 && USED >= PipeT::kDepth, "fragment pipeline needs USED % depth == 0");
+#if NS_OB16_DMA_SPREAD
+    constexpr int STRIDE = USED / PipeT::LPW > 0 ? USED / PipeT::LPW : 1;
+    pipe.begin_slab_no_issue();
+    pipe.template issue_piece<0>();
+#else
     pipe.begin_slab();
+#endif
     static_for<USED>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
+#if NS_OB16_DMA_SPREAD
+      if constexpr (p > 0 && p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece<p / STRIDE>();
+#endif
       auto load_next = [&] {
         if constexpr (p + PipeT::kDepth < USED)
           pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
@@ -384,6 +444,13 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
       };
       op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth], load_next);
     });
+#if NS_OB16_DMA_SPREAD
+    static_for<PipeT::LPW>([&](auto i_) {      // pieces a short slab had no chunk step for
+      constexpr int i = decltype(i_)::value;
+      if constexpr (i > 0 && i * STRIDE >= USED) pipe.template issue_piece<i>();
+    });
+    pipe.issue_advance();
+#endif
   });
 }
 // ---- positional-encoding slots -------------------------------------------------------------------
@@ -560,6 +627,9 @@ struct Mma16BF16 {
   __device__ static __forceinline__ void mma(f32x4a& acc, const AFrag& a, const Block& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.v, acc, 0, 0, 0);
   }
+  __device__ static __forceinline__ void mma_c(f32x4a& acc, const AFrag& a, const Block& b, const f32x4a& c) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b.v, c, 0, 0, 0);
+  }
   __device__ static __forceinline__ Block from_f32(const float (&x)[8]) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 w = {pack2<false>(x[0], x[1]), pack2<false>(x[2], x[3]), pack2<false>(x[4], x[5]), pack2<false>(x[6], x[7])};
@@ -574,6 +644,9 @@ struct Mma16F16 {
   __device__ static __forceinline__ uint32_t pack2(float a, float b) { return MmaF16::pack2<RELU>(a, b); }
   __device__ static __forceinline__ void mma(f32x4a& acc, const AFrag& a, const Block& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.v, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ void mma_c(f32x4a& acc, const AFrag& a, const Block& b, const f32x4a& c) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b.v, c, 0, 0, 0);
   }
   __device__ static __forceinline__ Block from_f32(const float (&x)[8]) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -621,10 +694,14 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
   constexpr int CONV_END = (PIECES + PPS - 1) / PPS;
   constexpr int BIAS_AT = (NKB - 2) > CONV_END ? (NKB - 2) : (NKB - 1);
   f32x4a c[2][T];
+#if NS_OB16_BIAS_C
+  f32x4a bnext = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);   // bias of the sub-block about to start
+#else
   {
     const f32x4a b0 = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);
     static_for<T>([&](auto t_) { c[0][decltype(t_)::value] = b0; });
   }
+#endif
   // A lone wave issues in order: an instruction placed after the MFMA cluster overlaps only the LAST MFMA's
   // execution (16 cycles for this shape), one placed between two MFMAs hides in the wait for the matrix pipe.  So the
   // step is emitted as MFMA / conversion piece / MFMA / fragment read / MFMA / bias / MFMA with scheduling fences.
@@ -635,21 +712,38 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
       const typename M::AFrag frag = frag_ref;
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
+#if NS_OB16_BIAS_C
+        if constexpr (kc == 0) M::mma_c(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}), bnext);
+        else M::mma(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}));
+#else
         M::mma(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}));
+#endif
 #if NS_OB16_INTERLEAVE
         __builtin_amdgcn_sched_barrier(0);
 #endif
         if constexpr (t == 0 && sb > 0) {
           static_for<PPS>([&](auto i_) {
             constexpr int piece = kc * PPS + decltype(i_)::value;
-            if constexpr (piece < PIECES)
+            if constexpr (piece < PIECES) {
+#ifdef NS_EXP_NOCONV       // timing ablation: finished sub-blocks are not converted (results are wrong)
+              const f32x4a keep = c[par ^ 1][piece % T];
+              auto& ob = out[piece % T][(sb - 1) >> 1].v;      // stays "defined" so that later layers are not folded away
+              asm volatile("" : "+v"(ob) : "v"(keep));
+#else
               convert_piece16<M, ACT, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
+#endif
+            }
           });
         }
         if constexpr (t == (T > 1 ? 1 : 0)) load_next();
         if constexpr (t == (T > 2 ? 2 : T - 1) && kc == BIAS_AT && sb + 1 < NSB) {
+#if NS_OB16_BIAS_C
+          static_assert(BIAS_AT > 0, "the bias register is read by the first chunk's MFMAs");
+          bnext = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
+#else
           const f32x4a bn = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
           static_for<T>([&](auto u_) { c[par ^ 1][decltype(u_)::value] = bn; });
+#endif
         }
       });
     } else {
@@ -803,6 +897,126 @@ __device__ __forceinline__ void gather3_16(typename M::Block (&out)[NKB], const 
       x[e] = col >= 0 ? row[col] : 0.0f;
     });
     out[kb] = M::from_f32(x);
+  });
+}
+
+}  // namespace nsmlp
+
+// =================================================================================================
+// Split-operand layers on the same 16x16x32 engine ("f16x3"): fp32-grade products at 1/3 of the fp16 MFMA rate.
+// Every operand is carried as an unevaluated sum of two fp16 values, x = hi + lo with hi = fp16(x), lo = fp16(x - hi)
+// (22 significant bits together), and a product term is three MFMAs: W_hi x_hi + W_hi x_lo + W_lo x_hi (the dropped
+// W_lo x_lo is 2^-22 relative).  Accumulation stays fp32 in the matrix core, as in the fp32 MFMA path, which this
+// path matches to fp32 rounding (tests: the fp32 gates) at ~4-5x its rate.  fp16's exponent range bounds the
+// operands: |x| < 65504 (the packer refuses weights beyond it), and below ~1e-4 the lo half goes subnormal, i.e. the
+// absolute error floor is ~3e-8 per operand -- the size of fp32's own rounding of O(1) values.
+// Stream order (ns_pack.hip, layout 16 with split operands): per K-block the W_hi chunk then the W_lo chunk, so a
+// layer has 2 NKB chunks per sub-block and the generic stream_chunks<> walk applies unchanged.
+namespace nsmlp {
+
+struct Mma16F16x3 {
+  static constexpr int kDtype = 3;
+  using AFrag = f16x8;
+  struct Block { f16x8 hi, lo; };                    // one lane's 8 features of a 32-feature K-block, split
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __device__ static __forceinline__ void mma(f32x4a& acc, const AFrag& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  }
+  // (a, b) -> packed hi pair, packed lo pair
+  __device__ static __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 ab = {a, b};
+    const f16x2 h = __builtin_convertvector(ab, f16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    const f32x2 rest = ab - back;                     // exact: hi is the nearest fp16, the remainder fits fp32
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rest, f16x2));
+  }
+  __device__ static __forceinline__ Block from_f32(const float (&x)[8]) {
+    u32x4 h, l;
+    static_for<4>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      uint32_t a, b;
+      split2(x[2 * i], x[2 * i + 1], a, b);
+      h[i] = a; l[i] = b;
+    });
+    Block r;
+    r.hi = __builtin_bit_cast(f16x8, h);
+    r.lo = __builtin_bit_cast(f16x8, l);
+    return r;
+  }
+};
+
+// dword J (0..1) of the finished sub-block SB of one tile -> dword 2 (SB & 1) + J of K-block SB >> 1, both halves
+template <int ACT, int SB, int J>
+__device__ __forceinline__ void convert_piece16x3(Mma16F16x3::Block& out, const f32x4a& c) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  float a = c[2 * J], b = c[2 * J + 1];
+  if constexpr (ACT == kRelu) { a = __builtin_fmaxf(a, 0.0f); b = __builtin_fmaxf(b, 0.0f); }
+  if constexpr (ACT == kLeaky) { a = __builtin_fmaxf(a, 0.01f * a); b = __builtin_fmaxf(b, 0.01f * b); }
+  uint32_t h, l;
+  Mma16F16x3::split2(a, b, h, l);
+  u32x4 wh = __builtin_bit_cast(u32x4, out.hi), wl = __builtin_bit_cast(u32x4, out.lo);
+  wh[2 * (SB & 1) + J] = h;
+  wl[2 * (SB & 1) + J] = l;
+  out.hi = __builtin_bit_cast(f16x8, wh);
+  out.lo = __builtin_bit_cast(f16x8, wl);
+}
+
+// layer_ob16<> for split operands: stream chunk 2 kc of a sub-block is W_hi of K-block kc (two MFMAs per tile:
+// x_hi, x_lo), chunk 2 kc + 1 is W_lo (one MFMA per tile: x_hi).  Conversion pieces (one per tile and dword) are
+// spread over the chunk steps of the following sub-block as in layer_ob16<>.
+template <int T, int NSB, int NKB, int ACT, class PipeT, class OutT, class InF>
+__device__ __forceinline__ void layer_ob16x3(PipeT& pipe, const float* bias_lds, int g, OutT& out, f32x4a (&last)[T], InF&& in) {
+  using M = Mma16F16x3;
+  constexpr int CPS = 2 * NKB;                        // chunks per sub-block
+  constexpr int REAL = NSB * CPS;
+  constexpr int TOTAL = ob16_chunks(NSB, CPS, PipeT::kDepth);
+  constexpr int PIECES = 2 * T;
+  constexpr int PPS = (PIECES + CPS - 1) / CPS;
+  constexpr int CONV_END = (PIECES + PPS - 1) / PPS;
+  constexpr int BIAS_AT = (CPS - 2) > CONV_END ? (CPS - 2) : (CPS - 1);
+  f32x4a c[2][T];
+  {
+    const f32x4a b0 = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);
+    static_for<T>([&](auto t_) { c[0][decltype(t_)::value] = b0; });
+  }
+  stream_chunks<TOTAL>(pipe, [&](auto P_, const typename M::AFrag& frag_ref, auto&& load_next) {
+    constexpr int P = decltype(P_)::value;
+    if constexpr (P < REAL) {
+      constexpr int sb = P / CPS, cc = P % CPS, kc = cc / 2, part = cc % 2, par = sb & 1;
+      const typename M::AFrag frag = frag_ref;
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        const typename M::Block& xb = in(t_, std::integral_constant<int, kc>{});
+        M::mma(c[par][t], frag, xb.hi);
+        if constexpr (part == 0) M::mma(c[par][t], frag, xb.lo);
+        if constexpr (t == 0 && sb > 0) {
+          static_for<PPS>([&](auto i_) {
+            constexpr int piece = cc * PPS + decltype(i_)::value;
+            if constexpr (piece < PIECES)
+              convert_piece16x3<ACT, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
+          });
+        }
+        if constexpr (t == (T > 1 ? 1 : 0)) load_next();
+        if constexpr (t == T - 1 && cc == BIAS_AT && sb + 1 < NSB) {
+          const f32x4a bn = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
+          static_for<T>([&](auto u_) { c[par ^ 1][decltype(u_)::value] = bn; });
+        }
+      });
+    } else {
+      load_next();
+    }
+  });
+  static_for<T>([&](auto t_) { last[decltype(t_)::value] = c[(NSB - 1) & 1][decltype(t_)::value]; });
+}
+template <int ACT, int T, int NSB, class OutT>
+__device__ __forceinline__ void convert_last16x3(OutT& out, const f32x4a (&last)[T]) {
+  static_for<T>([&](auto t_) {
+    static_for<2>([&](auto j_) {
+      convert_piece16x3<ACT, NSB - 1, decltype(j_)::value>(out[decltype(t_)::value][(NSB - 1) >> 1], last[decltype(t_)::value]);
+    });
   });
 }
 

@@ -1,10 +1,9 @@
-// Radiance-field MLP forward for the 16-bit operand paths (bf16 / f16) on v_mfma_f32_16x16x32: the shape that
-// sustains the most under the MI355X power cap (tools/mfma_peak.hip: 2.14 vs 1.87 PFLOP/s for 32x32x16 with live
-// operands).  Same operator as ns_nerf_mlp.hip (run_network + NeRF.forward, Trainer.py:789-806 and
-// run_nerf_helpers.py:67-134): positional encoding of points and view directions, DxW trunk with the input skip,
-// (feature o view) layer carrying the sigma head as one extra output row, rgb head, one persistent kernel.  A wave owns T = 4 tiles of 16 samples (64 samples);
-// every A fragment (16 output rows x 32 input features, 1 KiB) read from LDS feeds 4 MFMAs; layers are walked one
-// 16-row output sub-block at a time (layer_ob16 in ns_mlp_engine.h; weight stream layout 16 of ns_pack.hip).
+// Radiance-field MLP forward with SPLIT fp16 operands ("f16x3", NS_DTYPE_F16X3): the program of ns_nerf_mlp_ob16.hip
+// (same operator, same folded layers, same 16x16x32 engine and weight ring) with every operand carried as a hi + lo
+// pair of fp16 values and every product term as three MFMAs (layer_ob16x3 in ns_mlp_engine.h).  fp32-grade results
+// (the fp32 parity gates apply: raw <= 2e-5 of scale, config-1 frame 1e-4) at about a third of the fp16 rate, i.e.
+// several times the exact-fp32 MFMA path.  A wave owns T = 2 tiles of 16 samples: the hi/lo activation pairs of two
+// tiles fill the registers four plain tiles do.
 #include "ns_common.h"
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
@@ -13,10 +12,10 @@ namespace {
 
 using namespace nsmlp;
 
-constexpr int kT = 4;        // 16-sample tiles per wave
+constexpr int kT = 2;        // 16-sample tiles per wave (hi + lo activation blocks: half the tiles of the plain kernel)
 constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + accumulators per wave
 
-struct Nerf16Args {
+struct NerfX3Args {
   const char* stream;
   const float* bias;
   uint32_t n_slabs;
@@ -34,9 +33,10 @@ struct Nerf16Args {
   float* raw;
 };
 
-template <class M, int NKB, bool EMBEDDED>   // NKB = W / 32 K-blocks of a hidden layer
+template <int NKB, bool EMBEDDED>   // NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
-nerf_mlp_ob16_kernel(Nerf16Args a) {
+nerf_mlp_x3_kernel(NerfX3Args a) {
+  using M = Mma16F16x3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int T = kT, NWAVES = kWaves, NSB = 2 * NKB;   // 16-row output sub-blocks of a hidden layer
   using Block = typename M::Block;
@@ -53,14 +53,15 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   typedef typename M::AFrag __attribute__((address_space(3))) * StashPtr;
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(smem)));
   const uint32_t stash_region = lds0 + PipeT::kLdsBytes + ((static_cast<uint32_t>(a.bias_floats) * 4u + 15u) & ~15u);
-  const uint32_t stash_base = stash_region + static_cast<uint32_t>(wave) * (T * 3 * 1024) + static_cast<uint32_t>(lane) * 16u;
-  auto stash_at = [&](int t, int b) -> StashPtr {
-    return reinterpret_cast<StashPtr>(static_cast<uintptr_t>(stash_base + (t * 3 + b) * 1024));
+  // per wave T x 3 blocks x (hi 1 KiB, lo 1 KiB)
+  const uint32_t stash_base = stash_region + static_cast<uint32_t>(wave) * (T * 3 * 2048) + static_cast<uint32_t>(lane) * 16u;
+  auto stash_at = [&](int t, int b, int half) -> StashPtr {
+    return reinterpret_cast<StashPtr>(static_cast<uintptr_t>(stash_base + ((t * 3 + b) * 2 + half) * 1024));
   };
-  auto stash_put = [&](int t, int b, const Block& v) { *stash_at(t, b) = v.v; };
-  auto stash_get = [&](int t, int b) -> Block { Block v; v.v = *stash_at(t, b); return v; };
+  auto stash_put = [&](int t, int b, const Block& v) { *stash_at(t, b, 0) = v.hi; *stash_at(t, b, 1) = v.lo; };
+  auto stash_get = [&](int t, int b) -> Block { Block v; v.hi = *stash_at(t, b, 0); v.lo = *stash_at(t, b, 1); return v; };
   // staging: value slot k (0..9) of sample j (0..63) of this wave's group at stage_base + k * 256 + j * 4
-  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (10 * 256);
+  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 2048) + static_cast<uint32_t>(wave) * (10 * 256);
 
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
@@ -79,7 +80,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   auto prefetch = [&](int64_t grp) {
     if constexpr (!EMBEDDED) {
       bool valid;
-      const int64_t sidx = sample_of(grp, lane >> 4, lane & 15, valid);
+      const int64_t sidx = sample_of(grp, (lane >> 4) % T, lane & 15, valid);   // (upper lanes re-fetch, harmlessly)
       const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
                                             : sidx / a.N;
       auto put = [&](int slot, const float* src) {
@@ -127,8 +128,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
-        embed3_16<M, false, 10, 2>(xe[t], p[0], p[1], p[2], g);
-        embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
+        embedN_16<M, true, 3, 10, 2>(xe[t], p, g);
+        embedN_16<M, true, 3, 4, 1>(ve, v, g);
       }
       stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, ve[0]);
     });
@@ -149,24 +150,24 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     };
 
     // layer 0: x -> hA
-    layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
+    layer_ob16x3<T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16x3<true, T, NSB>(hA, last); bias += NSB * 16;
     // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
     // have been consumed (they fed the embeddings above)
     prefetch(grp + gridDim.x);
     int l = 1;
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     for (; l + 1 < a.D; l += 2) {
-      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
-      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
-      convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
-      if (l == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB);
-      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
-      convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
+      if (l - 1 == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
+      convert_last16x3<true, T, NSB>(hB, last); bias += NSB * 16;
+      if (l == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB);
+      else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
+      convert_last16x3<true, T, NSB>(hA, last); bias += NSB * 16;
     }
     if (l < a.D) {  // odd layer left over: hA -> hB, then move back
-      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
-      else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
-      convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
+      if (l - 1 == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
+      convert_last16x3<true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
     }
     // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
@@ -177,10 +178,10 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
     };
     float sigma[T];
-    layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
+    layer_ob16x3<T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
     // rgb (W/2 -> 3): rows 0..2 (lane group 0, registers 0..2)
-    layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
+    layer_ob16x3<T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
 
     if (g == 0) {
       static_for<T>([&](auto t_) {
@@ -194,20 +195,21 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   ring.finish();
 }
 
-int ob16_program_slabs(int W, int D, int skip) {
+int x3_program_slabs(int W, int D, int skip) {   // two stream chunks (W_hi, W_lo) per K-block
   const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
-  int n = ob16_layer_slabs(NSB, 2, dp);
-  for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, (l - 1 == skip) ? NKB + 2 : NKB, dp);
-  n += ob16_layer_slabs(NSB / 2 + 1, NKB + 1, dp) + ob16_layer_slabs(1, NKB / 2, dp);
+  int n = ob16_layer_slabs(NSB, 2 * 2, dp);
+  for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, 2 * ((l - 1 == skip) ? NKB + 2 : NKB), dp);
+  n += ob16_layer_slabs(NSB / 2 + 1, 2 * (NKB + 1), dp) + ob16_layer_slabs(1, 2 * (NKB / 2), dp);
   return n;
 }
 
-template <class M, int NKB, bool EMB>
-int launch(Nerf16Args& a, hipStream_t stream) {
+template <int NKB, bool EMB>
+int launch(NerfX3Args& a, hipStream_t stream) {
+  using M = Mma16F16x3;
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
-                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
-                     static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash | input staging
-  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB>;
+                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 2048 +
+                     static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash (hi, lo) | input staging
+  auto kern = nerf_mlp_x3_kernel<NKB, EMB>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
   const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
@@ -219,36 +221,24 @@ int launch(Nerf16Args& a, hipStream_t stream) {
   return NS_OK;
 }
 
-template <class M, bool EMB>
-int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
-  return net->width == 256 ? launch<M, 8, EMB>(a, stream) : launch<M, 4, EMB>(a, stream);
-}
-
 }  // namespace
 
+// called by ns_nerf_forward_ob16 for NS_DTYPE_F16X3 handles (arguments validated by its callers)
 int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                       float* raw_dev, hipStream_t stream);
-
-// called by ns_nerf_forward / ns_nerf_forward_embedded for handles packed with layout 16 (arguments validated there)
-int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
-                         const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                         float* raw_dev, hipStream_t stream) {
-  if (net->dtype == NS_DTYPE_F16X3)   // split fp16 operands: ns_nerf_mlp_x3.hip
-    return ns_nerf_forward_x3(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, x90_dev, S, N, raw_dev, stream);
-  if (ob16_program_slabs(net->width, net->depth, net->skip) != static_cast<int>(net->n_slabs)) {
+                       float* raw_dev, hipStream_t stream) {
+  if (x3_program_slabs(net->width, net->depth, net->skip) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
-                  ob16_program_slabs(net->width, net->depth, net->skip));
+                  x3_program_slabs(net->width, net->depth, net->skip));
     return NS_E_INVALID;
   }
-  Nerf16Args a{};
+  NerfX3Args a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
   a.D = net->depth; a.skip = net->skip;
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
-  const bool emb = x90_dev != nullptr;
-  if (net->dtype == NS_DTYPE_BF16) return emb ? dispatch_m<Mma16BF16, true>(net, a, stream) : dispatch_m<Mma16BF16, false>(net, a, stream);
-  if (net->dtype == NS_DTYPE_F16) return emb ? dispatch_m<Mma16F16, true>(net, a, stream) : dispatch_m<Mma16F16, false>(net, a, stream);
-  return NS_E_UNSUPPORTED;
+  const bool emb = x90_dev != nullptr, wide = net->width == 256;
+  if (emb) return wide ? launch<8, true>(a, stream) : launch<4, true>(a, stream);
+  return wide ? launch<8, false>(a, stream) : launch<4, false>(a, stream);
 }

@@ -49,7 +49,10 @@ struct Builder {
   std::vector<uint8_t> bytes;
   std::vector<float> bias;
 
-  explicit Builder(int dt) : dtype(dt), cpb(dt == NS_DTYPE_F32 ? 4 : 2), epc(dt == NS_DTYPE_F32 ? 4 : 8) {}
+  bool split = false;   // NS_DTYPE_F16X3: every layout-16 chunk is followed by the chunk of its fp16 remainders
+
+  explicit Builder(int dt) : dtype(dt == NS_DTYPE_F16X3 ? NS_DTYPE_F16 : dt), cpb(dt == NS_DTYPE_F32 ? 4 : 2),
+                             epc(dt == NS_DTYPE_F32 ? 4 : 8), split(dt == NS_DTYPE_F16X3) {}
 
   void put(uint8_t* lane_base, int elem, float v) const {
     if (dtype == NS_DTYPE_F32) {
@@ -118,15 +121,35 @@ struct Builder {
       }
     }
   }
+  // remainder chunk of a split-operand stream: lo = fp16(w - float(fp16(w))), same lane layout as the hi chunk
+  void fill_chunk16_lo(uint8_t* chunk, const float* Wm, int out_f, int in_f, int sb, int kb,
+                       const std::function<int(int)>& colmap) const {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int n = 16 * sb + (lane & 15), g = lane >> 4;
+      for (int e = 0; e < 8; ++e) {
+        const int col = colmap(nsmlp::feature16(kb, g, e));
+        float v = 0.0f;
+        if (n < out_f && col >= 0) {
+          const float w = Wm[static_cast<size_t>(n) * in_f + col];
+          v = w - static_cast<float>(static_cast<_Float16>(w));
+        }
+        put(chunk + lane * 16, e, v);
+      }
+    }
+  }
   void layer_ob16(const float* Wm, int out_f, int in_f, int nsb, const std::vector<Seg>& segs) {
     const size_t base = bytes.size();
     size_t n = 0;
     for (int sb = 0; sb < nsb; ++sb)
       for (const Seg& sg : segs)
         for (int kb = 0; kb < sg.nblk; ++kb) {
-          bytes.resize(base + (n + 1) * kChunkBytes, 0);
+          bytes.resize(base + (n + 1 + (split ? 1 : 0)) * kChunkBytes, 0);
           fill_chunk16(bytes.data() + base + n * kChunkBytes, Wm, out_f, in_f, sb, kb, sg.colmap);
           ++n;
+          if (split) {
+            fill_chunk16_lo(bytes.data() + base + n * kChunkBytes, Wm, out_f, in_f, sb, kb, sg.colmap);
+            ++n;
+          }
         }
     // zero chunks up to the fragment pipeline depth (the kernel walks them without MFMAs), then to a slab boundary
     const size_t padded = (n + nsmlp::kOb16Depth - 1) / nsmlp::kOb16Depth * nsmlp::kOb16Depth;
@@ -259,6 +282,13 @@ void fold_depthnet_front(int n_branch, const int* hidden_sizes, int C0, const fl
   fb32 = to_f32(fb);
 }
 
+// fp16-operand streams (NS_DTYPE_F16, NS_DTYPE_F16X3): a weight beyond fp16's range would become +-inf silently
+bool fits_f16(const float* w, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (!(std::fabs(w[i]) < 65504.0f) && !std::isnan(w[i])) return false;
+  return true;
+}
+
 int finish(Builder& b, ns_weights* w) {
   w->n_slabs = static_cast<uint32_t>(b.bytes.size() / kSlabBytes);
   w->bias_floats = static_cast<int>(b.bias.size());
@@ -282,7 +312,7 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   NS_REQUIRE(out && w && b, "null pointer");
   *out = nullptr;
   if (!(W == 128 || W == 256) || D < 1 || D > 64 || skip < -1 || (skip >= 0 && skip >= D - 1) ||
-      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16)) {
+      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
     ns::set_error("ns_pack_nerf: unsupported network (W=%d D=%d skip=%d dtype=%d); kernels exist for "
                   "W in {128,256}, one optional skip before the last layer, input_ch 63/27", W, D, skip, dtype);
     return NS_E_UNSUPPORTED;
@@ -363,7 +393,7 @@ int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, cons
   NS_REQUIRE(out && w && b && hidden_sizes && cat_sizes, "null pointer");
   *out = nullptr;
   if (n_branch < 1 || n_branch > 64 || n_trunk < 1 || n_trunk > 64 ||
-      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16)) {
+      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
     ns::set_error("ns_pack_depthnet: unsupported network (n_branch=%d n_trunk=%d dtype=%d)", n_branch, n_trunk, dtype);
     return NS_E_UNSUPPORTED;
   }

@@ -33,13 +33,60 @@ def batchify(fn, chunk):
     return ret
 
 
+class _HostSink:
+    """Frame-sized pinned host buffers that the per-chunk host copies of render_rays_test (the reference's four
+    `.cpu()` calls per chunk, nerf_utils.py:866-870) land in directly, asynchronously, on a side stream.
+
+    The reference serialises the GPU on every chunk (a blocking D2H of ~42 MB at 32768 rays x 64 samples) and then
+    concatenates the chunks on the host (another pass over ~0.8 GB per 800x800 frame).  Here chunk i's copies overlap
+    chunk i+1's kernels and the "concatenation" is the buffer itself; the caller gets the same host tensors (same keys,
+    shapes, dtypes, values).  Buffers come from torch's caching pinned allocator, fresh per frame, so tensors returned
+    for one frame are never overwritten by the next (render_path keeps references across frames)."""
+
+    def __init__(self, total_rows: int, device):
+        self.total, self.device = int(total_rows), torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.bufs, self.keep, self.row0 = {}, [], 0
+
+    def put(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        n = t.shape[0]
+        buf = self.bufs.get(key)
+        if buf is None:
+            # device="cpu" explicitly: the experiment scripts switch torch's DEFAULT device to cuda (utils.py:143-149)
+            buf = self.bufs[key] = torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device="cpu",
+                                               pin_memory=True)
+        dst = buf[self.row0 : self.row0 + n]
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(done)
+            dst.copy_(t, non_blocking=True)
+        self.keep.append(t)              # the device tensor stays alive until finish()
+        return dst
+
+    def advance(self, n_rows: int):
+        self.row0 += int(n_rows)
+
+    def finish(self):
+        self.stream.synchronize()
+        self.keep.clear()
+
+
 def _batchify(render_fn, rays_flat, chunk, **kwargs):
     all_returned = {}
+    sink = None
+    if render_fn is render_rays_test and rays_flat.is_cuda and not kwargs.get("_blocking_host_copies", False):
+        sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device)
     for i in range(0, rays_flat.shape[0], chunk):
         returned = render_fn(rays_flat[i : i + chunk], **kwargs)
         for key in returned:
             all_returned.setdefault(key, []).append(returned[key])
-    return {key: torch.cat(all_returned[key], 0) for key in all_returned}
+        if sink is not None:
+            sink.advance(min(chunk, rays_flat.shape[0] - i))
+    if sink is not None:
+        sink.finish()
+    return {key: (sink.bufs[key] if sink is not None and key in sink.bufs else torch.cat(all_returned[key], 0))
+            for key in all_returned}
 
 
 def batchify_rays(rays_flat, chunk=1024 * 32, **kwargs):
@@ -254,6 +301,10 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
     rays_o, rays_d = ray_batch[:, 0:3].contiguous(), ray_batch[:, 3:6].contiguous()
     viewdirs = ray_batch[:, -3:].contiguous() if ray_batch.shape[-1] > 8 else None
     ret = {}
+    # host copies (nerf_utils.py:820-822, 866-870): blocking `.cpu()` when called on its own; inside batchify_rays_test
+    # they go asynchronously into the frame's pinned buffers (_HostSink)
+    sink = kwargs.get("_host_sink")
+    to_host = (lambda key, t: sink.put(key, t)) if sink is not None else (lambda key, t: t.cpu())
     if trainer.compare_nerf or trainer.use_nerf_max_pts or trainer.use_full_nerf:
         (_dens, fine_z, fine_pts, fine_rgb, fine_w, _al, fine_disp, fine_raw) = sample_as_in_NeRF(
             ray_batch=ray_batch, N_samples=N_samples, network_fn=network_fn, network_fine=network_fine,
@@ -261,7 +312,8 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
             lindisp=lindisp, white_bkgd=white_bkgd, pytest=pytest, kwargs=kwargs)
         max_z_vals, max_weights, max_rgb_map = ops.argmax_gather(fine_w, fine_z, fine_raw)
         max_pts = ops.points_along_rays(rays_o, rays_d, max_z_vals)
-        ret["max_z_vals"], ret["max_pts"], ret["max_weights"] = max_z_vals.cpu(), max_pts.cpu(), max_weights.cpu()
+        ret["max_z_vals"], ret["max_pts"] = to_host("max_z_vals", max_z_vals), to_host("max_pts", max_pts)
+        ret["max_weights"] = to_host("max_weights", max_weights)
     if trainer.use_nerf_max_pts:
         rgb_map, disp_map = max_rgb_map, torch.zeros_like(max_rgb_map)  # [R,3] disp: reference quirk, :826
         weights, pts, z_vals = max_weights, max_pts, max_z_vals
@@ -277,8 +329,8 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
         (rgb_map, disp_map, _acc, _depth, _density, _alphas, weights) = trainer.raw2outputs(
             raw=raw, z_vals=z_vals, rays_d=rays_d, raw_noise=raw_noise_std, white_bkdg=white_bkgd, pytest=pytest)
     ret["depth_net_rgb_map"] = rgb_map
-    ret["depth_net_weights"] = weights.cpu()
-    ret["depth_net_disp_map"] = disp_map.cpu()
-    ret["depth_net_z_vals"] = z_vals.cpu()
-    ret["depth_net_pts"] = pts.cpu()
+    ret["depth_net_weights"] = to_host("depth_net_weights", weights)
+    ret["depth_net_disp_map"] = to_host("depth_net_disp_map", disp_map)
+    ret["depth_net_z_vals"] = to_host("depth_net_z_vals", z_vals)
+    ret["depth_net_pts"] = to_host("depth_net_pts", pts)
     return ret

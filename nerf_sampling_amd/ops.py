@@ -20,7 +20,8 @@ Tensor = torch.Tensor
 
 _DTYPES = {"f32": _lib.DTYPE_F32, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32,
            "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16,
-           "f16": _lib.DTYPE_F16, "fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16}
+           "f16": _lib.DTYPE_F16, "fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16,
+           "f16x3": _lib.DTYPE_F16X3}     # split fp16 operands: fp32-grade results on the 16-bit engine
 _MODES = {"depth_only": _lib.MODE_DEPTH_ONLY, "uniform": _lib.MODE_UNIFORM, "gaussian": _lib.MODE_GAUSSIAN}
 
 _compute_dtype = "f32"

@@ -142,8 +142,9 @@ class Trainer:
         return avg_test_psnr
 
     def train(self, N_iters=200000 + 1):
-        """render_only path of Trainer.train (Trainer.py:712-750): load data, build / reload the networks,
-        render the test (or spiral) poses, return the average PSNR.  The optimisation loop is out of scope."""
+        """Trainer.train (Trainer.py:712-787): load data, build / reload the networks; render_only: render the test
+        (or spiral) poses and return the average PSNR; otherwise the DepthNet optimisation loop (random ray batches from
+        one image, or -- use_batching -- from the shuffled rays of all training images), checkpoints every i_weights."""
         hwf, poses, i_test, i_val, i_train, images, render_poses = self.load_data()
         dev = "cuda" if self.device == "cuda" else self.device
         if self.render_test:

@@ -252,11 +252,14 @@ def _mlp_err(ops, gpu_modules, golden, scene, dtype):
 
 
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
-def test_nerf_mlp_f32(ops, gpu_modules, golden, scene):
-    """fp32 MFMA path: exact-fp32 products, k-ordered fma chain; only summation order differs from the CPU GEMM."""
-    for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, "f32").items():
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_nerf_mlp_f32(ops, gpu_modules, golden, scene, dtype):
+    """fp32 MFMA path: exact-fp32 products, k-ordered fma chain; only summation order differs from the CPU GEMM.
+    f16x3 (split fp16 operands, three MFMAs per product term on the 16x16x32 engine) is held to the SAME gate."""
+    for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, dtype).items():
         scale = np.abs(exp).max(axis=(0, 1))             # per output channel (rgb ~ O(1), sigma ~ O(100))
         err = np.abs(mine - exp).max(axis=(0, 1)) / scale
+        print(f"nerf_mlp {dtype} {scene} {which}: max err/scale {err}")
         assert (err < 2e-5).all(), (which, err)
 
 
@@ -291,7 +294,7 @@ def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
         view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
         ref = ops.nerf_forward(net.packed("f32"), pts, view).cpu().numpy()
         scale = np.abs(ref).reshape(-1, 4).max(0) + 1e-6
-        for dtype, tol in (("bf16", 0.15), ("f16", 0.03)):   # max error over all samples; a wrong program gives O(1)
+        for dtype, tol in (("bf16", 0.15), ("f16", 0.03), ("f16x3", 1e-4)):   # max error over all samples; a wrong program gives O(1)
             got = ops.nerf_forward(net.packed(dtype), pts, view).cpu().numpy()
             assert got.shape == (R, N, 4) and np.isfinite(got).all()
             err = np.abs(got - ref).reshape(-1, 4).max(0) / scale
@@ -353,6 +356,18 @@ def test_depthnet_16bit(ops, gpu_modules, golden, scene, dtype, tol):
     assert np.sqrt((err ** 2).mean()) < tol, float(np.sqrt((err ** 2).mean()))
 
 
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_depthnet_f16x3(ops, gpu_modules, golden, scene):
+    """split fp16 operands: the fp32 gate (2e-4 abs on z in [2,6]), NaN rows kept"""
+    g = golden("depthnet")
+    z = ops.depthnet_forward(gpu_modules(scene)["depth"].packed("f16x3"), dev(g["o"]), dev(g["d"]))
+    exp = g[f"z_{scene}"]
+    assert torch.isnan(z[256:258]).all()
+    ok = ~np.isnan(exp[:, 0])
+    print(f"depthnet f16x3 {scene}: max |z err| {np.abs(z.cpu().numpy() - exp)[ok].max():.3e}")
+    close(z, exp, 0, 2e-4)
+
+
 def test_depthnet_ragged_sizes(ops, gpu_modules):
     m = gpu_modules("tiny_synth")
     gen = torch.Generator().manual_seed(12)
@@ -389,6 +404,6 @@ def test_depthnet_shapes_vs_oracle(ops, hidden, cat):
         if R == 300:
             assert float(exp.std()) > 0.05                  # the depth really varies across rays
         close(ops.depthnet_forward(dn.packed("f32"), o.cuda(), d.cuda()), exp, 0, 2e-4)
-        for dtype, tol in (("bf16", 3e-2), ("f16", 4e-3)):
+        for dtype, tol in (("bf16", 3e-2), ("f16", 4e-3), ("f16x3", 2e-4)):
             z = ops.depthnet_forward(dn.packed(dtype), o.cuda(), d.cuda())
             assert float((z.cpu() - exp).abs().max()) < tol, (dtype, R, float((z.cpu() - exp).abs().max()))

@@ -119,10 +119,13 @@ def test_render_rays_test_sampling_setups(golden, gpu_modules, ns, mode, dist):
         assert bad <= 0.03 and np.median(err) < 5e-5, (k, bad, float(err.max()))
 
 
-def test_frame_config1_fp32_gate(golden, gpu_modules):
-    """BASELINE config 1 (64x64, 32 samples/ray) through render_test, fp32 gate 1e-4 on rgb and disp."""
-    from nerf_sampling_amd import nerf_utils
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_frame_config1_fp32_gate(golden, gpu_modules, dtype):
+    """BASELINE config 1 (64x64, 32 samples/ray) through render_test, fp32 gate 1e-4 on rgb and disp -- for the
+    exact-fp32 MFMA path and for the split-fp16 path (f16x3) on the 16-bit engine, which is held to the same gate."""
+    from nerf_sampling_amd import nerf_utils, ops
 
+    ops.set_compute_dtype(dtype)
     g = golden("frame64")
     m = gpu_modules("lego_synth")
     tr = make_trainer(n_depth_samples=32, sampling_mode="uniform", distance=0.1)
@@ -146,7 +149,7 @@ def test_frame_config1_fp32_gate(golden, gpu_modules):
     ill = ill.numpy()
     err_rgb = np.abs(npy(rgb) - g["rgb"]).reshape(-1, 3).max(-1)
     err_disp = np.abs(npy(disp) - g["disp"]).reshape(-1) / np.maximum(np.abs(g["disp"]).reshape(-1), 1.0)
-    print(f"config1: ill-conditioned rays {ill.mean():.4f}, max rgb err on the rest {err_rgb[~ill].max():.2e}, "
+    print(f"config1 [{dtype}]: ill-conditioned rays {ill.mean():.4f}, max rgb err on the rest {err_rgb[~ill].max():.2e}, "
           f"overall median {np.median(err_rgb):.2e}")
     assert ill.mean() < 0.01
     assert err_rgb[~ill].max() <= 1e-4
@@ -478,3 +481,30 @@ def test_full_size_config5_fp16(gpu_modules):
     g2 = ops.render_rays_depthnet(m["depth"].packed("f16"), m["fine"].packed("f16"), camera=(H, W, K, c2w, 600, 800),
                                   n_samples=192, mode="gaussian", std=0.1, noise=noise, extras=True)
     assert torch.equal(g1["rgb"], g2["rgb"]) and (g1["z"][:, 1:] >= g1["z"][:, :-1]).all()
+
+
+@pytest.mark.parametrize("flags", [{}, dict(compare_nerf=True), dict(use_nerf_max_pts=True)])
+def test_async_host_copies_equal_blocking_copies(gpu_modules, flags):
+    """render_test's per-chunk host copies (nerf_utils.py:820-822, 866-870) through the pinned asynchronous sink return
+    exactly what the reference-style blocking `.cpu()` + host concatenation returns: same keys, shapes, devices, values,
+    over several ragged chunks, and a second frame does not overwrite the first one's tensors."""
+    from nerf_sampling_amd import nerf_utils
+
+    m = gpu_modules("tiny_synth")
+    H, W = 23, 31                                  # 713 rays in chunks of 200: 4 chunks, ragged tail
+    _, K = O.blender_intrinsics(H, W)
+    tr = make_trainer(n_depth_samples=16, sampling_mode="uniform", distance=0.1, **flags)
+    kw = render_kwargs(tr, m)
+    kw.update(near=2.0, far=6.0, ndc=False)
+    c2w = O.pose_spherical(77.0, -30.0, 4.0)[:3, :4]
+    a_rgb, a_disp, a = nerf_utils.render_test(H, W, K, chunk=200, c2w=c2w, **kw)
+    b_rgb, b_disp, b = nerf_utils.render_test(H, W, K, chunk=200, c2w=c2w, _blocking_host_copies=True, **kw)
+    keep = {k: v.clone() for k, v in a.items()}
+    nerf_utils.render_test(H, W, K, chunk=200, c2w=O.pose_spherical(-20.0, -30.0, 4.0)[:3, :4], **kw)   # another frame
+    assert torch.equal(a_rgb, b_rgb) and a_rgb.is_cuda
+    assert torch.equal(a_disp.cpu(), b_disp.cpu()) and a_disp.is_cuda == b_disp.is_cuda
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and a[k].is_cuda == b[k].is_cuda, k
+        assert torch.equal(a[k].cpu(), b[k].cpu()), k
+        assert torch.equal(a[k], keep[k]), k       # untouched by the later frame

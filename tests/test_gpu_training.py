@@ -211,3 +211,74 @@ def test_run_cli_counterpart(tmp_path, gpu_modules):
         assert "[TRAIN] Iter: 2" in res.output
     finally:
         torch.set_default_device("cpu")
+
+
+def test_use_batching_and_ray_dump(tmp_path, gpu_modules):
+    """The use_batching branch of the batch sampler (Trainer.py:232-269, 400-414): rays of all training images shuffled
+    once (numpy's generator, as the reference), N_rand rows per step, reshuffle after an epoch; and the safetensors ray
+    dump (sampling_trainer.py:124-138) round-tripped through safetensors' own loader."""
+    from safetensors.torch import load_file
+    from test_render_path import _write_dataset
+
+    from nerf_sampling_amd import ops
+    from nerf_sampling_amd.trainers import DepthNetTrainer
+
+    ops.set_compute_dtype("f32")
+    m = gpu_modules("tiny_synth")
+    rng = np.random.default_rng(4)
+    H = W = 12
+    frames = [np.concatenate([rng.integers(0, 256, (H, W, 3), dtype=np.uint8), np.full((H, W, 1), 255, np.uint8)], -1)
+              for _ in range(3)]
+    poses = [O.pose_spherical(a, -30.0, 4.0).numpy() for a in (10.0, 130.0, 250.0)]
+    data, logs = str(tmp_path / "data"), str(tmp_path / "logs")
+    _write_dataset(data, {"train": frames, "val": frames[:1], "test": frames[:1]},
+                   {"train": poses, "val": poses[:1], "test": poses[:1]})
+    nerf_ckpt = str(tmp_path / "nerf.tar")
+    both = list(m["coarse"].parameters()) + list(m["fine"].parameters())
+    torch.save({"global_step": 0, "network_fn_state_dict": m["coarse"].state_dict(),
+                "network_fine_state_dict": m["fine"].state_dict(),
+                "optimizer_state_dict": torch.optim.Adam(both).state_dict()}, nerf_ckpt)
+    kw = dict(dataset_type="blender", basedir=logs, expname="exp", no_batching=False, datadir=data, half_res=False,
+              white_bkgd=True, testskip=1, device="cuda", N_rand=100, N_importance=128, N_samples=64, use_viewdirs=True,
+              input_dims_embed=3, netdepth=4, netwidth=128, netdepth_fine=4, netwidth_fine=128, n_layers=3,
+              layer_width=128, sphere_radius=2.0, ft_path=nerf_ckpt, depth_net_lr=1e-3, train_depth_net_only=True,
+              i_weights=1000, i_print=1000, perturb=0.0)
+    tr = DepthNetTrainer(**kw)
+    assert tr.use_batching
+    hwf, ps, i_test, i_val, i_train, images, _ = tr.load_data()
+    tr.cast_intrinsics_to_right_types(hwf)
+    np.random.seed(11)
+    imgs_t, poses_t, rays_rgb, i_batch = tr.prepare_raybatch_tensor_if_batching_random_rays(ps, images, i_train)
+    n = len(i_train) * H * W
+    assert rays_rgb.shape == (n, 3, 3) and i_batch == 0 and rays_rgb.is_cuda
+    # the same permutation the reference's np.random.shuffle(rays_rgb) draws, applied to rays built by the oracle
+    np.random.seed(11)
+    perm = np.arange(n); np.random.shuffle(perm)
+    rows = []
+    for i in i_train:
+        o, d = O.camera_rays(H, W, tr.K, torch.tensor(np.asarray(ps[i]), dtype=torch.float32)[:3, :4])
+        rows.append(torch.stack([o.reshape(-1, 3), d.reshape(-1, 3),
+                                 torch.tensor(np.asarray(images[i]), dtype=torch.float32).reshape(-1, images[i].shape[-1])[:, :3]], 1))
+    exp = torch.cat(rows, 0)[torch.from_numpy(perm)]
+    assert torch.equal(rays_rgb[..., :].cpu()[:, 0], exp[:, 0])              # origins: bit exact
+    assert torch.allclose(rays_rgb.cpu(), exp, rtol=0, atol=2e-6)
+    seen = 0
+    for step in range(6):                                                     # 432 rays / 100 per step: wraps in step 5
+        rays_rgb, i_batch, batch_rays, target = tr.sample_random_ray_batch(rays_rgb, i_batch, i_train, imgs_t, poses_t, step)
+        assert batch_rays.shape[0] == 2 and batch_rays.shape[2] == 3 and target.shape == (batch_rays.shape[1], 3)
+        seen += batch_rays.shape[1]
+        if step < 4:
+            assert torch.equal(batch_rays[0].cpu(), exp[step * 100 : (step + 1) * 100, 0])
+    assert i_batch == 100 and seen == 100 * 4 + 32 + 100                      # reshuffled after the epoch, then continues
+    # the training loop itself runs on this branch
+    np.random.seed(0); torch.manual_seed(0)
+    psnr = DepthNetTrainer(**kw).train(N_iters=4)
+    assert psnr is not None and np.isfinite(float(psnr))
+    # ray dump
+    tr.global_step = 7
+    o = torch.randn(5, 3).cuda(); pts = torch.randn(5, 4, 3).cuda(); alpha = torch.rand(5, 4).cuda()
+    path = tr.save_rays_data(o, pts[:, ::2], alpha)                            # a non-contiguous view, as callers may pass
+    assert path.endswith(os.path.join("exp", "exp_7.safetensors"))
+    back = load_file(path)
+    assert set(back) == {"origins", "pts", "alpha"}
+    assert torch.equal(back["origins"], o.cpu()) and torch.equal(back["pts"], pts[:, ::2].cpu()) and torch.equal(back["alpha"], alpha.cpu())

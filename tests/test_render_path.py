@@ -47,22 +47,28 @@ def test_blender_loader_cpu(tmp_path):
 def test_render_only_pipeline_with_reference_checkpoints(tmp_path, gpu_modules):
     """yaml-style kwargs -> DepthNetTrainer.train() with render_only: reads a Blender dataset and .tar
     checkpoints in the reference's layout (utils.py:59-89), renders the test poses, writes NNN.png and
-    psnr.txt in the reference's format.  Ground truth = this build's own fp32 render (8-bit PNG)."""
+    psnr.txt in the reference's format.  Ground truth = the ORACLE's render of the same poses (CPU fp32, stored as the
+    dataset's 8-bit PNGs), so the PSNR the pipeline reports is build-vs-oracle: quantisation noise only."""
     from nerf_sampling_amd import ops
     from nerf_sampling_amd.synthetic import blender_intrinsics, pose_spherical
     from nerf_sampling_amd.utils import load_obj_from_config
+    from oracle import nerf_oracle as O
 
     ops.set_compute_dtype("f32")
     m = gpu_modules("tiny_synth")
+    P = m["params"]
     H = W = 32
     _, K = blender_intrinsics(H, W)
     data = str(tmp_path / "data"); logs = str(tmp_path / "logs")
     poses = [pose_spherical(a, -30.0, 4.0).numpy() for a in (10.0, 130.0)]
-    frames = []
+    frames, oracle_rgb = [], []
     for p in poses:
-        out = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"), camera=(H, W, K, p[:3, :4], 0, H),
-                                       n_samples=16, mode="uniform", std=0.1)
-        rgb = np.nan_to_num(out["rgb"].reshape(H, W, 3).cpu().numpy(), nan=1.0)
+        with torch.no_grad():
+            rgb, _disp, _ = O.render_frame(H, W, K, torch.from_numpy(p)[:3, :4], 1024 * 32, 2.0, 6.0, p_coarse=P["coarse"],
+                                           p_fine=P["fine"], p_depth=P["depth"], n_depth_samples=16,
+                                           sampling_mode="uniform", distance=0.1)
+        rgb = np.nan_to_num(rgb.reshape(H, W, 3).numpy(), nan=1.0)
+        oracle_rgb.append(rgb)
         frames.append(np.concatenate([(255 * np.clip(rgb, 0, 1)).round().astype(np.uint8),
                                       np.full((H, W, 1), 255, np.uint8)], -1))
     _write_dataset(data, {"train": frames[:1], "val": frames[:1], "test": frames}, {"train": poses[:1], "val": poses[:1], "test": poses})
@@ -88,7 +94,13 @@ def test_render_only_pipeline_with_reference_checkpoints(tmp_path, gpu_modules):
     assert sorted(f for f in os.listdir(out_dir) if f.endswith(".png")) == ["000.png", "001.png"]
     lines = open(os.path.join(out_dir, "psnr.txt")).read().splitlines()
     assert lines[0].startswith("000.png, PSNR: ") and lines[2] == "Avg of 2 images:" and lines[3].startswith("PSNR: ")
-    assert psnr > 50.0          # vs its own 8-bit ground truth: quantisation noise only (~59 dB)
+    assert psnr > 50.0          # vs the oracle's 8-bit frames: quantisation noise only (~59 dB)
+    from PIL import Image
+
+    for i, exp in enumerate(oracle_rgb):   # the written PNGs are the oracle's frames up to one 8-bit step
+        png = np.asarray(Image.open(os.path.join(out_dir, f"{i:03d}.png")), dtype=np.int32)
+        want = (255 * np.clip(exp, 0, 1)).astype(np.uint8).astype(np.int32)           # to8b truncates (run_nerf_helpers.py:11)
+        assert np.abs(png - want).max() <= 1 and np.mean(png != want) < 0.02
     sd = torch.load(os.path.join(out_dir, "scene_data.pt"), weights_only=True)
     assert sd["all_pts"].shape == (2 * H * W * 16, 3) and sd["all_weights"].shape == (2 * H * W * 16,)
 

@@ -1,13 +1,19 @@
+# tools/profile_round.sh [TAG]: the round's numbers of record on one box -- the default bench line, a rocprofv3 kernel
+# trace of the same command, and the PMC passes (each in its own run: counters never share a run with a trace domain
+# other than --kernel-trace).  Outputs under gpurun_out/TAG/; copy the summaries to profiles/.
 set -e
+tag=${1:-r02}
 root=$PWD
-mkdir -p gpurun_out/r01e
-python bench.py > gpurun_out/r01e/bench_default.json 2> gpurun_out/r01e/bench_default.err
-tail -1 gpurun_out/r01e/bench_default.json | cut -c1-400
+mkdir -p gpurun_out/$tag
+python bench.py > gpurun_out/$tag/bench_default.json 2> gpurun_out/$tag/bench_default.err
+tail -1 gpurun_out/$tag/bench_default.json | cut -c1-600
 cd /tmp && export TMPDIR=/tmp
-export NS_BENCH_NOCHECK=1   # profiled runs: no PSNR leg, so every launch in the CSVs is a full-frame launch
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/r01e/stats -- python $root/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $root/gpurun_out/r01e/bench_under_rocprof.json 2>$root/gpurun_out/r01e/stats.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $root/gpurun_out/r01e/pmc_sq -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$root/gpurun_out/r01e/pmc_sq.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/r01e/pmc_fetch -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$root/gpurun_out/r01e/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/r01e/pmc_write -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$root/gpurun_out/r01e/pmc_write.err
-rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $root/gpurun_out/r01e/pmc_inst -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>$root/gpurun_out/r01e/pmc_inst.err
-cd $root; find gpurun_out/r01e -name "*.csv" | head -20
+export NS_BENCH_NOCHECK=1   # profiled runs: no accuracy leg, so every launch in the CSVs is a full-frame launch
+B="python $root/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/$tag/stats -- $B --steps 5 --warmup 2 > $root/gpurun_out/$tag/bench_under_rocprof.json 2>$root/gpurun_out/$tag/stats.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $root/gpurun_out/$tag/pmc_sq -- $B --steps 2 --warmup 1 > /dev/null 2>$root/gpurun_out/$tag/pmc_sq.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/$tag/pmc_fetch -- $B --steps 2 --warmup 1 > /dev/null 2>$root/gpurun_out/$tag/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/$tag/pmc_write -- $B --steps 2 --warmup 1 > /dev/null 2>$root/gpurun_out/$tag/pmc_write.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d $root/gpurun_out/$tag/pmc_inst -- $B --steps 2 --warmup 1 > /dev/null 2>$root/gpurun_out/$tag/pmc_inst.err
+cd $root
+python tools/pmc_summary.py gpurun_out/$tag | tee gpurun_out/$tag/summary.txt
