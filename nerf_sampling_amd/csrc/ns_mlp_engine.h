@@ -37,6 +37,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef NS_OB16_DMA_SPREAD
 #define NS_OB16_DMA_SPREAD 0   // 1: a wave's four DMA pieces of a slab are issued a quarter slab apart instead of all after the barrier
 #endif
+#ifndef NS_OB16_LATE_REFILL
+#define NS_OB16_LATE_REFILL 1  // 1: a chunk step refills the fragment register of the previous chunk (one chunk less read-ahead, no WAR nops)
+#endif
 #ifndef NS_OB16_BIAS_C
 #define NS_OB16_BIAS_C 0       // 1: the bias is the C operand of a sub-block's first MFMA (no per-tile copies into the accumulators)
 #endif
@@ -436,12 +439,22 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
 #if NS_OB16_DMA_SPREAD
       if constexpr (p > 0 && p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece<p / STRIDE>();
 #endif
+#if NS_OB16_LATE_REFILL
+      // refill the slot of the PREVIOUS chunk (its MFMAs were all issued a step ago, so the LDS read does not have to
+      // wait out the write-after-read window of an MFMA that is still fetching its A operand): chunk p + DEPTH - 1
+      auto load_next = [&] {
+        constexpr int q = p + PipeT::kDepth - 1;
+        if constexpr (q < USED) pipe.template load<q * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.cur);
+        else pipe.template load<(q - USED) * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.nxt);
+      };
+#else
       auto load_next = [&] {
         if constexpr (p + PipeT::kDepth < USED)
           pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
         else
           pipe.template load<(p + PipeT::kDepth - USED) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.nxt);
       };
+#endif
       op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth], load_next);
     });
 #if NS_OB16_DMA_SPREAD

@@ -13,8 +13,15 @@ namespace {
 
 using namespace nsmlp;
 
-constexpr int kT = 4;        // 16-sample tiles per wave
-constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + accumulators per wave
+#ifndef NS_NERF16_T
+#define NS_NERF16_T 4
+#endif
+#ifndef NS_NERF16_WAVES
+#define NS_NERF16_WAVES 4
+#endif
+constexpr int kT = NS_NERF16_T;          // 16-sample tiles per wave
+constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of activations + accumulators per wave
+                                         // (8 waves x T = 2, two per SIMD in 256 registers each: measured slower)
 
 struct Nerf16Args {
   const char* stream;
@@ -79,7 +86,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   auto prefetch = [&](int64_t grp) {
     if constexpr (!EMBEDDED) {
       bool valid;
-      const int64_t sidx = sample_of(grp, lane >> 4, lane & 15, valid);
+      const int64_t sidx = sample_of(grp, (lane >> 4) % T, lane & 15, valid);   // (T < 4: the upper lanes re-fetch, harmlessly)
       const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
                                             : sidx / a.N;
       auto put = [&](int slot, const float* src) {

@@ -264,7 +264,7 @@ def test_nerf_mlp_f32(ops, gpu_modules, golden, scene, dtype):
 
 
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
-@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("f16", 4.5e-3)])     # measured rms/scale ~1e-2 / 1.5e-3 (sigma channel)
+@pytest.mark.parametrize("dtype,tol", [("bf16", 2.2e-2), ("f16", 2.7e-3)])   # measured rms/scale <= 7.1e-3 / 8.7e-4 (round 2)
 def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
     """16-bit operands, fp32 accumulation: error is operand rounding (2^-9 bf16, 2^-12 fp16) through ~10 layers."""
     for which, (mine, exp) in _mlp_err(ops, gpu_modules, golden, scene, dtype).items():
@@ -294,7 +294,9 @@ def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
         view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
         ref = ops.nerf_forward(net.packed("f32"), pts, view).cpu().numpy()
         scale = np.abs(ref).reshape(-1, 4).max(0) + 1e-6
-        for dtype, tol in (("bf16", 0.15), ("f16", 0.03), ("f16x3", 1e-4)):   # max error over all samples; a wrong program gives O(1)
+        # max error over all samples (measured 0.092 / 0.0127 / 1.9e-5, the largest at R = N = 1 where the scale is one
+        # sample's own value); a wrong program gives O(1)
+        for dtype, tol in (("bf16", 0.15), ("f16", 0.03), ("f16x3", 6e-5)):
             got = ops.nerf_forward(net.packed(dtype), pts, view).cpu().numpy()
             assert got.shape == (R, N, 4) and np.isfinite(got).all()
             err = np.abs(got - ref).reshape(-1, 4).max(0) / scale

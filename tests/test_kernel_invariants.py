@@ -35,14 +35,13 @@ def _gfx950_code_objects(path):
         pos = base + len(MAGIC)
 
 
-@pytest.fixture(scope="module")
-def nerf16_isa():
+def _isa_of(kernel_name: bytes):
     if not os.path.exists(LIB):
         pytest.skip("library not built")
     if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
         pytest.skip("llvm-objdump not available")
     for co in _gfx950_code_objects(LIB):
-        if b"nerf_mlp_ob16_kernel" not in co:
+        if kernel_name not in co:
             continue
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(co)
@@ -52,7 +51,12 @@ def nerf16_isa():
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name],
                                    capture_output=True, text=True, check=True).stdout
         return dis, notes
-    pytest.fail("no gfx950 code object with nerf_mlp_ob16_kernel in the library")
+    pytest.fail(f"no gfx950 code object with {kernel_name.decode()} in the library")
+
+
+@pytest.fixture(scope="module")
+def nerf16_isa():
+    return _isa_of(b"nerf_mlp_ob16_kernel")
 
 
 def _functions(dis):
@@ -88,3 +92,32 @@ def test_nerf16_kernels_use_no_scratch_and_no_full_dma_wait(nerf16_isa):
         m = re.search(re.escape(name) + r".*?\.private_segment_fixed_size:\s*(\d+)", notes, re.S)
         if m:
             assert int(m.group(1)) == 0
+
+
+def _check_mlp_kernels(dis, notes, name_part, n_expected, mfma_pat, min_mfma):
+    fns = {k: v for k, v in _functions(dis).items() if name_part in k}
+    assert len(fns) == n_expected, sorted(fns)
+    for name, ins in fns.items():
+        text = "\n".join(ins)
+        assert "scratch_" not in text, f"{name}: scratch access in the kernel"
+        assert sum(mfma_pat in i for i in ins) > min_mfma, name
+        full_waits = sum(bool(re.search(r"s_waitcnt vmcnt\(0\)(?! *lgkmcnt)|s_waitcnt vmcnt\(0\)$", i)) for i in ins)
+        assert full_waits <= 10, f"{name}: {full_waits} s_waitcnt vmcnt(0)"
+        m = re.search(re.escape(name) + r".*?\.private_segment_fixed_size:\s*(\d+)", notes, re.S)
+        if m:
+            assert int(m.group(1)) == 0
+
+
+def test_depthnet16_kernels_use_no_scratch_and_no_full_dma_wait():
+    """The folded DepthNet on the same engine: bf16, f16 and split-f16 (f16x3), W = 256 and 128 -- no scratch (round 1's
+    kernel spilled 91 VGPRs and kept a 655 MB global stash), no compiler-inserted full DMA wait in the slab loop."""
+    dis, notes = _isa_of(b"depthnet_ob16_kernel")
+    _check_mlp_kernels(dis, notes, "depthnet_ob16_kernel", 6, "v_mfma_f32_16x16x32", 500)
+
+
+def test_nerf_x3_kernels_use_no_scratch_and_no_full_dma_wait():
+    dis, notes = _isa_of(b"nerf_mlp_x3_kernel")
+    fns = {k: v for k, v in _functions(dis).items() if "nerf_mlp_x3_kernel" in k and "ELb0EE" in k}
+    assert len(fns) == 2, sorted(fns)
+    _check_mlp_kernels("\n".join(f"0000 <{k}>:\n" + "\n".join("\t" + i for i in v) for k, v in fns.items()), notes,
+                       "nerf_mlp_x3_kernel", 2, "v_mfma_f32_16x16x32_f16", 1500)
