@@ -37,6 +37,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef NS_OB16_DMA_SPREAD
 #define NS_OB16_DMA_SPREAD 0   // 1: a wave's four DMA pieces of a slab are issued a quarter slab apart instead of all after the barrier
 #endif
+#ifndef NS_OB16_PAIR_LOADS
+#define NS_OB16_PAIR_LOADS 0   // 1: fragment reads issued in pairs every other chunk step (half the lgkmcnt waits, one chunk less read-ahead)
+#endif
+#ifndef NS_DMA_SADDR
+#define NS_DMA_SADDR 1         // 1: SGPR-base LDS-DMA, one M0 write per slab (each wave fetches consecutive chunks)
+#endif
 #ifndef NS_OB16_LATE_REFILL
 #define NS_OB16_LATE_REFILL 1  // 1: a chunk step refills the fragment register of the previous chunk (one chunk less read-ahead, no WAR nops)
 #endif
@@ -218,12 +224,53 @@ struct Pipe {
   bool exp_no_dma = false;
 #endif
 
+  __device__ static __forceinline__ uint32_t next_slot(uint32_t slot) {
+    if constexpr ((RING & (RING - 1)) == 0) return (slot + 1) & (RING - 1);   // one s_and instead of compare + select
+    else return (slot + 1 == RING) ? 0u : slot + 1;
+  }
+
   // One slab: LPW LDS-DMA instructions per wave.  They are issued through inline asm on purpose: with the
   // __builtin_amdgcn_global_load_lds form the compiler's waitcnt pass sees an LDS store it cannot disambiguate and
   // puts an s_waitcnt vmcnt(0) in front of the next LDS read of EVERY slab step -- the wave then waits out the L2
   // round trip of the slab it has just requested, three slabs early, and the ring prefetches nothing (measured:
   // MFMA pipe busy 52-69 % with it).  The asm form leaves the ordering to the counted wait + barrier of begin_slab().
   __device__ __forceinline__ void issue() {
+#if NS_DMA_SADDR
+    // One M0 write per slab: wave w fetches the LPW CONSECUTIVE chunks w*LPW .. w*LPW+LPW-1 with the SGPR-base form of the
+    // instruction (address = s[base] + 32-bit lane offset + immediate), the immediate offset stepping through both the
+    // global and the LDS address.  Saves a 64-bit VALU add, an M0 write and its wait state per piece.
+    if constexpr (LPW * kChunkBytes <= 4096) {
+#ifdef NS_EXP_NODMA
+      if (!exp_no_dma)
+#endif
+      {
+        const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * (LPW * kChunkBytes);
+        const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * (LPW * kChunkBytes);
+        const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
+        const uint64_t base = reinterpret_cast<uint64_t>(src);
+        const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+        const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
+        static_assert(LPW == 1 || LPW == 2 || LPW == 4, "pieces per wave");
+        if constexpr (LPW == 4)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %1, %2\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:3072" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+        else if constexpr (LPW == 2)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %1, %2\n\t"
+                       "global_load_lds_dwordx4 %1, %2 offset:1024" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+        else
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+      }
+      issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
+      issue_slot = next_slot(issue_slot);
+      return;
+    }
+#endif
     // wave-uniform part of the address in SGPRs, per-lane part a constant 32-bit offset (lane * 16)
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
     const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
@@ -240,7 +287,7 @@ struct Pipe {
     for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
 #endif
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
-    issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
+    issue_slot = next_slot(issue_slot);
   }
 
   // the same slab, one DMA instruction at a time (spread over the chunk steps of the open slab by stream_chunks<> when
@@ -256,7 +303,7 @@ struct Pipe {
   }
   __device__ __forceinline__ void issue_advance() {
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
-    issue_slot = (issue_slot + 1 == RING) ? 0u : issue_slot + 1;
+    issue_slot = next_slot(issue_slot);
   }
   // begin_slab() without the refill: the caller issues the LPW pieces itself and then issue_advance()
   __device__ __forceinline__ void begin_slab_no_issue() {
@@ -264,7 +311,7 @@ struct Pipe {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     cur = lds_off + read_slot * kSlabBytes + lane * 16;
-    read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
+    read_slot = next_slot(read_slot);
     nxt = lds_off + read_slot * kSlabBytes + lane * 16;
   }
 
@@ -341,7 +388,7 @@ struct Pipe {
     asm volatile("" ::: "memory");
     issue();                                      // refill the slot the previous slab occupied
     cur = lds_off + read_slot * kSlabBytes + lane * 16;
-    read_slot = (read_slot + 1 == RING) ? 0u : read_slot + 1;
+    read_slot = next_slot(read_slot);
     nxt = lds_off + read_slot * kSlabBytes + lane * 16;
   }
 
@@ -439,7 +486,22 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
 #if NS_OB16_DMA_SPREAD
       if constexpr (p > 0 && p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece<p / STRIDE>();
 #endif
-#if NS_OB16_LATE_REFILL
+#if NS_OB16_PAIR_LOADS
+      // Two fragment reads every other step, the later-consumed one FIRST: the wait for the younger read then covers the
+      // older one too, so a pair costs one s_waitcnt instead of two.  Odd step p refills the slots of chunks p-2 and p-1
+      // (both fully issued) with chunks p+DEPTH-2 and p+DEPTH-1.
+      auto load_next = [&] {
+        if constexpr ((p & 1) == 1) {
+          constexpr int DD = PipeT::kDepth;
+          static_assert(DD % 2 == 0 && DD >= 4, "pairing needs an even number of fragment registers");
+          constexpr int qa = p + DD - 1, qb = p + DD - 2;
+          if constexpr (qa < USED) pipe.template load<qa * kChunkBytes>(pipe.f[qa % DD], pipe.cur);
+          else pipe.template load<(qa - USED) * kChunkBytes>(pipe.f[qa % DD], pipe.nxt);
+          if constexpr (qb < USED) pipe.template load<qb * kChunkBytes>(pipe.f[qb % DD], pipe.cur);
+          else pipe.template load<(qb - USED) * kChunkBytes>(pipe.f[qb % DD], pipe.nxt);
+        }
+      };
+#elif NS_OB16_LATE_REFILL
       // refill the slot of the PREVIOUS chunk (its MFMAs were all issued a step ago, so the LDS read does not have to
       // wait out the write-after-read window of an MFMA that is still fetching its A operand): chunk p + DEPTH - 1
       auto load_next = [&] {

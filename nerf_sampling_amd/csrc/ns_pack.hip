@@ -318,6 +318,16 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     return NS_E_UNSUPPORTED;
   }
   for (int i = 0; i < D + 4; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
+  if (dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) {   // fp16 operands: refuse what would silently become +-inf
+    bool ok = true;
+    for (int l = 0; l < D && ok; ++l) ok = fits_f16(w[l], static_cast<size_t>(W) * (l == 0 ? 63 : (l - 1 == skip ? W + 63 : W)));
+    ok = ok && fits_f16(w[D], static_cast<size_t>(W) * W) && fits_f16(w[D + 1], W) &&
+         fits_f16(w[D + 2], static_cast<size_t>(W / 2) * (W + 27)) && fits_f16(w[D + 3], static_cast<size_t>(3) * (W / 2));
+    if (!ok) {
+      ns::set_error("ns_pack_nerf: a weight exceeds fp16's range (65504); use bf16 or f32 operands for this network");
+      return NS_E_UNSUPPORTED;
+    }
+  }
   const int NB = W / 32;
   Builder bl(dtype);
   auto ident = [](int k) { return k; };
@@ -326,6 +336,10 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   const int HV = W / 2, KV = W + 27;
   std::vector<float> wvf, bvf;
   fold_nerf_views(W, w[D], b[D], w[D + 2], b[D + 2], wvf, bvf);
+  if ((dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) && !fits_f16(wvf.data(), wvf.size())) {
+    ns::set_error("ns_pack_nerf: a folded views-layer weight exceeds fp16's range (65504); use bf16 or f32 operands");
+    return NS_E_UNSUPPORTED;
+  }
   if (layout == 0) {
     // layer 0: 63 -> W
     bl.add_bias(b[0], W, NB);
@@ -419,6 +433,15 @@ int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, cons
   //    to ONE width Wp in {128, 256}: a padded row has zero weights and bias, LeakyReLU(0) = 0 feeds zero columns
   const int W = cmax <= 128 ? 128 : 256, NB = W / 32;
   const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;
+  if (dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) {   // fp16 operands: refuse what would silently become +-inf
+    bool ok = fits_f16(F32.data(), F32.size());
+    for (int i = 1; i < n_trunk && ok; ++i) ok = fits_f16(w[t0 + i], static_cast<size_t>(cat_sizes[i]) * cat_sizes[i - 1]);
+    ok = ok && fits_f16(w[t0 + n_trunk], cat_sizes[n_trunk - 1]);
+    if (!ok) {
+      ns::set_error("ns_pack_depthnet: a (folded) weight exceeds fp16's range (65504); use bf16 or f32 operands");
+      return NS_E_UNSUPPORTED;
+    }
+  }
   Builder bl(dtype);
   auto padded_ident = [](int in_f) { return [in_f](int k) { return k < in_f ? k : -1; }; };
   if (layout == 0) {

@@ -33,6 +33,20 @@ def test_unsupported_network_shapes_raise():
         net(torch.zeros(8, 90).cuda())
 
 
+def test_fp16_operand_range_is_checked_at_pack_time():
+    """fp16-operand handles (f16, f16x3) refuse weights beyond fp16's range instead of packing +-inf; bf16 / f32 take them."""
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+    net = NeRF(D=2, W=128, input_ch=63, input_ch_views=27, skips=[], use_viewdirs=True)
+    with torch.no_grad():
+        net.alpha_linear.weight[0, 5] = 1.0e5
+    net = net.cuda()
+    for dt in ("f16", "f16x3"):
+        with pytest.raises(NotImplementedError, match="fp16"):
+            net.packed(dt)
+    net.packed("bf16"); net.packed("f32")
+
+
 def test_default_depthnet_shape_contract():
     """tests.py:188-194: output is [n_rays, 1] (with a supported configuration)."""
     from nerf_sampling_amd.depth_net import DepthNet
