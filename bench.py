@@ -207,7 +207,7 @@ def accuracy_vs_oracle(ops, depth_w, nerf_w, ref, H, W, K, c2w, n_samples, dtype
                                f"mask: oracle colour moves > 1e-2 under a sigma shift of +-{eps:.3g} (3x measured {dtype} noise)"}
 
 
-def api_path_rate(fine, dn, params, scene, dtype, H, W, K, poses, n_samples, device, frames=4, blocking=False):
+def api_path_rate(fine, dn, params, scene, dtype, H, W, K, poses, n_samples, device, frames=6, blocking=False):
     """What a user of the mirrored reference API gets: nerf_utils.render_test (render_rays_test in 32768-ray chunks,
     per-sample extras, the reference's per-chunk host copies of weights / disp / z / pts, nerf_utils.py:866-870) timed
     over whole frames INCLUDING those device-to-host copies (~0.8 GB per 800x800x64 frame).  blocking=True: the copies
@@ -227,12 +227,12 @@ def api_path_rate(fine, dn, params, scene, dtype, H, W, K, poses, n_samples, dev
               use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, trainer=tr, lindisp=True, depth_network=dn,
               model_mode="test", near=2.0, far=6.0, ndc=False, _blocking_host_copies=blocking)
     with torch.no_grad():
-        for i in range(2):
+        for i in range(2 if blocking else 4):    # the pinned-buffer cache of the async sink takes three frames to fill
             nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], **kw)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         for i in range(frames):
-            rgb, disp, extras = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[(2 + i) % 40], **kw)
+            rgb, disp, extras = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[(4 + i) % 40], **kw)
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / frames
     host_bytes = sum(v.numel() * v.element_size() for v in extras.values() if isinstance(v, torch.Tensor) and not v.is_cuda)
@@ -338,7 +338,7 @@ def main():
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (not live);
     # only quoted for the exact workload they were collected on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02b_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r02c_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]

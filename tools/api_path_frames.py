@@ -1,0 +1,32 @@
+"""Per-frame wall times of the mirrored-API path (nerf_utils.render_test, 800x800, N = 64, bf16) with the asynchronous
+pinned host sink: shows warm-up effects of the pinned allocator and the steady state."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from nerf_sampling_amd import nerf_utils, ops, synthetic
+from nerf_sampling_amd.run_nerf_helpers import get_embedder
+from nerf_sampling_amd.trainers import DepthNetTrainer
+
+dev = torch.device("cuda", 0)
+fine, dn, params = bench.build_modules("lego_synth", dev)
+H = W = 800
+_, K = synthetic.blender_intrinsics(H, W)
+poses = synthetic.render_poses(40)[:, :3, :4]
+ops.set_compute_dtype("bf16")
+tr = DepthNetTrainer(dataset_type="blender", basedir="/tmp", expname="x", no_batching=True, datadir="", half_res=False,
+                     white_bkgd=True, N_importance=128, N_samples=64, use_viewdirs=True, input_dims_embed=3, device="cuda",
+                     n_depth_samples=64, sampling_mode="uniform", distance=0.1)
+e1, _ = get_embedder(10, 0, 3); e2, _ = get_embedder(4, 0, 3)
+q = lambda i, v, f: tr.run_network(i, v, f, embed_fn=e1, embeddirs_fn=e2, netchunk=tr.netchunk)
+kw = dict(network_query_fn=q, perturb=0.0, N_importance=128, network_fine=fine, N_samples=64, network_fn=fine, use_viewdirs=True,
+          white_bkgd=True, raw_noise_std=0.0, trainer=tr, lindisp=True, depth_network=dn, model_mode="test", near=2.0, far=6.0,
+          ndc=False)
+with torch.no_grad():
+    for blocking in (False, True):
+        ts = []
+        for i in range(10):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            rgb, disp, ex = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], _blocking_host_copies=blocking, **kw)
+            torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
+        print("blocking" if blocking else "async   ", " ".join(f"{t:6.1f}" for t in ts))
