@@ -338,7 +338,7 @@ def main():
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (not live);
     # only quoted for the exact workload they were collected on
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02c_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r02d_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]

@@ -811,15 +811,19 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
           });
         }
         if constexpr (t == (T > 1 ? 1 : 0)) load_next();
-        if constexpr (t == (T > 2 ? 2 : T - 1) && kc == BIAS_AT && sb + 1 < NSB) {
 #if NS_OB16_BIAS_C
-          static_assert(BIAS_AT > 0, "the bias register is read by the first chunk's MFMAs");
+        // the next sub-block's bias is fetched right after this sub-block's first chunk (whose MFMAs read the current
+        // one as their C operand), a whole sub-block ahead of its use: no LDS latency in front of the first MFMA
+        if constexpr (t == T - 1 && kc == (NKB > 1 ? 1 : 0) && sb + 1 < NSB) {
+          static_assert(NKB > 1, "the bias register is read by the first chunk's MFMAs");
           bnext = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
+        }
 #else
+        if constexpr (t == (T > 2 ? 2 : T - 1) && kc == BIAS_AT && sb + 1 < NSB) {
           const f32x4a bn = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
           static_for<T>([&](auto u_) { c[par ^ 1][decltype(u_)::value] = bn; });
-#endif
         }
+#endif
       });
     } else {
       load_next();

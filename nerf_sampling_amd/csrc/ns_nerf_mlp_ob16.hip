@@ -16,6 +16,9 @@ using namespace nsmlp;
 #ifndef NS_NERF16_T
 #define NS_NERF16_T 4
 #endif
+#ifndef NS_NERF16_RELOAD_ONCE
+#define NS_NERF16_RELOAD_ONCE 1   // 1: stashed embeddings come back from LDS once per layer, not once per sub-block
+#endif
 #ifndef NS_NERF16_WAVES
 #define NS_NERF16_WAVES 4
 #endif
@@ -146,6 +149,27 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     auto in_x = [&](auto t_, auto kb_) -> const Block& { return xe[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
+#if NS_NERF16_RELOAD_ONCE
+    // The skip layer sees cat[x, h]: the embedded point comes back from the per-wave LDS stash ONCE per layer into
+    // registers (32 of them, live for that layer only) instead of once per 16-row sub-block -- 8 reads instead of 128
+    // per wave pass, none of them right in front of the MFMA that needs it.
+    Block xs[T][2];
+    auto load_xs = [&] {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        xs[t][0] = stash_get(t, 0); xs[t][1] = stash_get(t, 1);
+      });
+    };
+    auto in_xA = [&](auto t_, auto kb_) -> const Block& {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < 2) return xs[decltype(t_)::value][kb]; else return hA[decltype(t_)::value][kb - 2];
+    };
+    auto in_xB = [&](auto t_, auto kb_) -> const Block& {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < 2) return xs[decltype(t_)::value][kb]; else return hB[decltype(t_)::value][kb - 2];
+    };
+#else
+    auto load_xs = [&] {};
     auto in_xA = [&](auto t_, auto kb_) -> Block {
       constexpr int kb = decltype(kb_)::value;
       if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hA[decltype(t_)::value][kb - 2];
@@ -154,6 +178,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       constexpr int kb = decltype(kb_)::value;
       if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hB[decltype(t_)::value][kb - 2];
     };
+#endif
 
     // layer 0: x -> hA
     layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
@@ -163,15 +188,15 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     int l = 1;
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     for (; l + 1 < a.D; l += 2) {
-      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      if (l - 1 == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
-      if (l == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB);
+      if (l == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
       convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
     }
     if (l < a.D) {  // odd layer left over: hA -> hB, then move back
-      if (l - 1 == a.skip) layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      if (l - 1 == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
@@ -179,10 +204,19 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
     // cat[h, dirs27] -> W/2, relu: (hA, ve) -> hB[0 .. NKB/2); alpha_linear rides along as row 0 of one extra, LAST
     // sub-block, whose raw accumulators come back in `last`: sigma = row 0 (lane group 0, register 0)
+#if NS_NERF16_RELOAD_ONCE
+    Block vs[T];   // the embedded view direction, once for the layer's 9 sub-blocks
+    static_for<T>([&](auto t_) { vs[decltype(t_)::value] = stash_get(decltype(t_)::value, 2); });
+    auto in_Av = [&](auto t_, auto kb_) -> const Block& {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
+    };
+#else
     auto in_Av = [&](auto t_, auto kb_) -> Block {
       constexpr int kb = decltype(kb_)::value;
       if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
     };
+#endif
     float sigma[T];
     layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });

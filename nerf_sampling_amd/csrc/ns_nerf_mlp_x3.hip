@@ -140,13 +140,21 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
     auto in_x = [&](auto t_, auto kb_) -> const Block& { return xe[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
-    auto in_xA = [&](auto t_, auto kb_) -> Block {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hA[decltype(t_)::value][kb - 2];
+    // the skip layer's embedded point comes back from the LDS stash once per layer (see ns_nerf_mlp_ob16.hip)
+    Block xs[T][2];
+    auto load_xs = [&] {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        xs[t][0] = stash_get(t, 0); xs[t][1] = stash_get(t, 1);
+      });
     };
-    auto in_xB = [&](auto t_, auto kb_) -> Block {
+    auto in_xA = [&](auto t_, auto kb_) -> const Block& {
       constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hB[decltype(t_)::value][kb - 2];
+      if constexpr (kb < 2) return xs[decltype(t_)::value][kb]; else return hA[decltype(t_)::value][kb - 2];
+    };
+    auto in_xB = [&](auto t_, auto kb_) -> const Block& {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (kb < 2) return xs[decltype(t_)::value][kb]; else return hB[decltype(t_)::value][kb - 2];
     };
 
     // layer 0: x -> hA
@@ -157,15 +165,15 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
     int l = 1;
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     for (; l + 1 < a.D; l += 2) {
-      if (l - 1 == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      if (l - 1 == a.skip) { load_xs(); layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16x3<true, T, NSB>(hB, last); bias += NSB * 16;
-      if (l == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB);
+      if (l == a.skip) { load_xs(); layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB); }
       else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
       convert_last16x3<true, T, NSB>(hA, last); bias += NSB * 16;
     }
     if (l < a.D) {  // odd layer left over: hA -> hB, then move back
-      if (l - 1 == a.skip) layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA);
+      if (l - 1 == a.skip) { load_xs(); layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16x3<true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
@@ -173,9 +181,11 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
     // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
     // cat[h, dirs27] -> W/2, relu: (hA, ve) -> hB[0 .. NKB/2); alpha_linear rides along as row 0 of one extra, LAST
     // sub-block, whose raw accumulators come back in `last`: sigma = row 0 (lane group 0, register 0)
-    auto in_Av = [&](auto t_, auto kb_) -> Block {
+    Block vs[T];   // the embedded view direction, once for the layer
+    static_for<T>([&](auto t_) { vs[decltype(t_)::value] = stash_get(decltype(t_)::value, 2); });
+    auto in_Av = [&](auto t_, auto kb_) -> const Block& {
       constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
+      if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
     };
     float sigma[T];
     layer_ob16x3<T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
