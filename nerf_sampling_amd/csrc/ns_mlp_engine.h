@@ -301,6 +301,26 @@ struct Pipe {
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
     lds_dma16(src + I * NWAVES * kChunkBytes + lane_off, dst + I * NWAVES * kChunkBytes);
   }
+  // SGPR-base form of one piece (NS_OB16_DMA_SPREAD == 2): wave w owns the LPW consecutive chunks w*LPW .. of the slab
+  // being fetched; piece I is one instruction with immediate offset I KiB on both addresses.  M0 is rewritten in the
+  // same statement (the compiler does not preserve it between statements).
+  template <int I>
+  __device__ __forceinline__ void issue_piece_saddr() {
+    static_assert(I >= 0 && I < LPW && LPW * kChunkBytes <= 4096, "piece index");
+#ifdef NS_EXP_NODMA
+    if (exp_no_dma) return;
+#endif
+    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * (LPW * kChunkBytes);
+    const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * (LPW * kChunkBytes);
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
+    const uint64_t base = reinterpret_cast<uint64_t>(src);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+    const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(lane_off), "s"(sbase),
+                 "n"(I * kChunkBytes) : "memory");
+  }
   __device__ __forceinline__ void issue_advance() {
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = next_slot(issue_slot);
@@ -474,7 +494,10 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
     constexpr int s = decltype(s_)::value;
     constexpr int USED = (TOTAL - s * kSlabChunks) < kSlabChunks ? (TOTAL - s * kSlabChunks) : kSlabChunks;
     static_assert(USED % PipeT::kDepth == 0 && USED >= PipeT::kDepth, "fragment pipeline needs USED % depth == 0");
-#if NS_OB16_DMA_SPREAD
+#if NS_OB16_DMA_SPREAD == 2
+    constexpr int STRIDE = USED / PipeT::LPW > 0 ? USED / PipeT::LPW : 1;
+    pipe.begin_slab_no_issue();
+#elif NS_OB16_DMA_SPREAD
     constexpr int STRIDE = USED / PipeT::LPW > 0 ? USED / PipeT::LPW : 1;
     pipe.begin_slab_no_issue();
     pipe.template issue_piece<0>();
@@ -483,14 +506,22 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
 #endif
     static_for<USED>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
-#if NS_OB16_DMA_SPREAD
+#if NS_OB16_DMA_SPREAD == 1
       if constexpr (p > 0 && p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece<p / STRIDE>();
 #endif
+      // NS_OB16_DMA_SPREAD == 2: this slab's refill pieces ride with the fragment read, i.e. they are issued right after
+      // the step's second MFMA, when the matrix pipe has work queued, instead of all four behind the barrier where it is empty
+      auto dma_here = [&] {
+#if NS_OB16_DMA_SPREAD == 2
+        if constexpr (p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece_saddr<p / STRIDE>();
+#endif
+      };
 #if NS_OB16_PAIR_LOADS
       // Two fragment reads every other step, the later-consumed one FIRST: the wait for the younger read then covers the
       // older one too, so a pair costs one s_waitcnt instead of two.  Odd step p refills the slots of chunks p-2 and p-1
       // (both fully issued) with chunks p+DEPTH-2 and p+DEPTH-1.
       auto load_next = [&] {
+        dma_here();
         if constexpr ((p & 1) == 1) {
           constexpr int DD = PipeT::kDepth;
           static_assert(DD % 2 == 0 && DD >= 4, "pairing needs an even number of fragment registers");
@@ -505,12 +536,14 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
       // refill the slot of the PREVIOUS chunk (its MFMAs were all issued a step ago, so the LDS read does not have to
       // wait out the write-after-read window of an MFMA that is still fetching its A operand): chunk p + DEPTH - 1
       auto load_next = [&] {
+        dma_here();
         constexpr int q = p + PipeT::kDepth - 1;
         if constexpr (q < USED) pipe.template load<q * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.cur);
         else pipe.template load<(q - USED) * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.nxt);
       };
 #else
       auto load_next = [&] {
+        dma_here();
         if constexpr (p + PipeT::kDepth < USED)
           pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
         else
@@ -519,7 +552,10 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
 #endif
       op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth], load_next);
     });
-#if NS_OB16_DMA_SPREAD
+#if NS_OB16_DMA_SPREAD == 2
+    static_assert((PipeT::LPW - 1) * STRIDE < USED, "every piece has a chunk step");
+    pipe.issue_advance();
+#elif NS_OB16_DMA_SPREAD
     static_for<PipeT::LPW>([&](auto i_) {      // pieces a short slab had no chunk step for
       constexpr int i = decltype(i_)::value;
       if constexpr (i > 0 && i * STRIDE >= USED) pipe.template issue_piece<i>();
