@@ -69,8 +69,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   };
   auto stash_put = [&](int t, int b, const Block& v) { *stash_at(t, b) = v.v; };
   auto stash_get = [&](int t, int b) -> Block { Block v; v.v = *stash_at(t, b); return v; };
-  // staging: value slot k (0..9) of sample j (0..63) of this wave's group at stage_base + k * 256 + j * 4
-  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (10 * 256);
+  // staging: value slot k (0..9) of sample j (0 .. 16 T - 1) of this wave's group at stage_base + k * kStageRow + j * 4
+  constexpr uint32_t kStageRow = (T > 4 ? 2 : 1) * 256;
+  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (10 * kStageRow);
 
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
@@ -86,30 +87,35 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   // Inputs of the NEXT group are fetched right after layer 0 of the current one by LDS-DMA (no registers held across
   // the network): lane j of the wave fetches the ten values of the j-th of the wave's 64 consecutive samples.
   // pts mode: p 0..2, v 7..9;  (o, d, z) mode: o 0..2, d 3..5, z 6, v 7..9.
+  auto prefetch_round = [&](int64_t grp, int tile0) {     // the 64 lanes fetch tiles tile0 .. tile0 + 3 (clamped to T - 1)
+    bool valid;
+    const int tl = tile0 + (lane >> 4);
+    const int64_t sidx = sample_of(grp, tl < T ? tl : T - 1, lane & 15, valid);   // (surplus lanes re-fetch, harmlessly)
+    const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
+                                          : sidx / a.N;
+    auto put = [&](int slot, const float* src) {
+      lds_dma4(src, stage_base + slot * kStageRow + tile0 * 64);
+    };
+    if (a.pts) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) put(c, a.pts + sidx * 3 + c);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
+      put(6, a.z + sidx);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+  };
   auto prefetch = [&](int64_t grp) {
     if constexpr (!EMBEDDED) {
-      bool valid;
-      const int64_t sidx = sample_of(grp, (lane >> 4) % T, lane & 15, valid);   // (T < 4: the upper lanes re-fetch, harmlessly)
-      const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
-                                            : sidx / a.N;
-      auto put = [&](int slot, const float* src) {
-        lds_dma4(src, stage_base + slot * 256);
-      };
-      if (a.pts) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put(c, a.pts + sidx * 3 + c);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
-        put(6, a.z + sidx);
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+      prefetch_round(grp, 0);
+      if constexpr (T > 4) prefetch_round(grp, 4);
     }
   };
   auto staged = [&](int t, int slot) -> float {
     return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
-        static_cast<uintptr_t>(stage_base + slot * 256 + (t * 16 + n) * 4));
+        static_cast<uintptr_t>(stage_base + slot * kStageRow + (t * 16 + n) * 4));
   };
 
   prefetch(blockIdx.x);
@@ -247,7 +253,11 @@ template <class M, int NKB, bool EMB>
 int launch(Nerf16Args& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
-                     static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash | input staging
+                     static_cast<size_t>(kWaves) * 10 * (kT > 4 ? 512 : 256);   // ring | bias | embedding stash | input staging
+  if (lds > 160 * 1024) {
+    ns::set_error("ns_nerf_forward: %zu bytes of LDS needed (too deep a network for the resident bias image)", lds);
+    return NS_E_UNSUPPORTED;
+  }
   auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
