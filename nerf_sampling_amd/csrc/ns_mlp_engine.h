@@ -157,7 +157,7 @@ struct MmaF32 {
   template <bool RELU = false>
   __device__ static __forceinline__ void from_f32(Block& b, const float (&x)[16]) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) b.v[j] = RELU ? fmaxf(x[j], 0.0f) : x[j];
+    for (int j = 0; j < 16; ++j) b.v[j] = RELU ? (x[j] < 0.0f ? 0.0f : x[j]) : x[j];   // NaN stays NaN, as torch.relu (fmaxf would drop it)
   }
   __device__ static __forceinline__ void relu_packed(Block&) {}
   using AFrag = f32x4;
@@ -1068,7 +1068,7 @@ template <int ACT, int SB, int J>
 __device__ __forceinline__ void convert_piece16x3(Mma16F16x3::Block& out, const f32x4a& c) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   float a = c[2 * J], b = c[2 * J + 1];
-  if constexpr (ACT == kRelu) { a = __builtin_fmaxf(a, 0.0f); b = __builtin_fmaxf(b, 0.0f); }
+  if constexpr (ACT == kRelu) { a = a < 0.0f ? 0.0f : a; b = b < 0.0f ? 0.0f : b; }   // NaN stays NaN, as torch.relu
   if constexpr (ACT == kLeaky) { a = __builtin_fmaxf(a, 0.01f * a); b = __builtin_fmaxf(b, 0.01f * b); }
   uint32_t h, l;
   Mma16F16x3::split2(a, b, h, l);

@@ -55,7 +55,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
 
-  // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 10 x 256 B]
+  // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 10 rows of 16 T floats]
   float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
   for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
   __syncthreads();
@@ -122,6 +122,11 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     Block xe[T][2];   // embedded point (63 -> 64 features); registers for layer 0 only
+    // Non-finite inputs: the reference's arithmetic turns a NaN / inf coordinate into NaN in all four outputs (sin / cos,
+    // nn.Linear and torch.relu all propagate it).  Here the packed-int16 ReLU would drop the NEGATIVE NaNs the matrix
+    // cores produce, so the samples are flagged (bit t of `bad`, one register across the network) and written as NaN.
+    uint32_t bad = 0;
+    auto finite = [](float v) { return __builtin_fabsf(v) < __builtin_inff(); };
     asm volatile("" ::: "memory");   // the staged inputs landed several slab steps ago (in-order vmcnt)
     static_for<T>([&](auto t_) {
       constexpr int t = decltype(t_)::value;
@@ -131,6 +136,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         const float* row = a.x90 + sample_of(grp, t, n, valid) * 90;
         gather3_16<M, 10, 2>(xe[t], row, g);
         gather3_16<M, 4, 1>(ve, row + 63, g);
+        if (!(finite(row[0]) && finite(row[1]) && finite(row[2]) && finite(row[63]) && finite(row[64]) && finite(row[65])))
+          bad |= 1u << t;
       } else {
         float p[3], v[3];
         if (a.pts) {
@@ -143,6 +150,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
+        if (!(finite(p[0]) && finite(p[1]) && finite(p[2]) && finite(v[0]) && finite(v[1]) && finite(v[2]))) bad |= 1u << t;
         embed3_16<M, false, 10, 2>(xe[t], p[0], p[1], p[2], g);
         embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
       }
@@ -234,7 +242,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         constexpr int t = decltype(t_)::value;
         bool valid;
         const int64_t sidx = sample_of(grp, t, n, valid);
-        if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = make_float4(last[t][0], last[t][1], last[t][2], sigma[t]);
+        float4 o4 = make_float4(last[t][0], last[t][1], last[t][2], sigma[t]);
+        if ((bad >> t) & 1u) { const float q = __builtin_nanf(""); o4 = make_float4(q, q, q, q); }
+        if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
       });
     }
   }

@@ -409,3 +409,17 @@ def test_depthnet_shapes_vs_oracle(ops, hidden, cat):
         for dtype, tol in (("bf16", 3e-2), ("f16", 4e-3), ("f16x3", 2e-4)):
             z = ops.depthnet_forward(dn.packed(dtype), o.cuda(), d.cuda())
             assert float((z.cpu() - exp).abs().max()) < tol, (dtype, R, float((z.cpu() - exp).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16", "f16"])
+def test_nerf_mlp_nan_points_stay_nan(ops, gpu_modules, dtype):
+    """A NaN sample point (a ray that misses the DepthNet's sphere gives NaN depths, utils.py:159-217) comes out as NaN
+    raw values, as torch.relu / nn.Linear propagate it in the reference -- and only for that sample."""
+    m = gpu_modules("tiny_synth")
+    pts = torch.rand(3, 5, 3) * 2 - 1
+    pts[1, 2, 0] = float("nan")
+    view = torch.nn.functional.normalize(torch.randn(3, 3), dim=-1)
+    raw = ops.nerf_forward(m["fine"].packed(dtype), pts.cuda(), view.cuda()).cpu()
+    assert torch.isnan(raw[1, 2]).all(), raw[1, 2]
+    ok = torch.ones(3, 5, dtype=torch.bool); ok[1, 2] = False
+    assert torch.isfinite(raw[ok]).all()

@@ -581,3 +581,26 @@ def test_config3_band_vs_oracle(gpu_modules, dtype):
         assert float((zerr > 5e-3).float().mean()) <= 0.05
     else:   # measured (round 2): median 6.8e-4, PSNR 65.7 dB, no ray off by 1e-2, z median 1.2e-3
         assert float(err.median()) < 2e-3 and _psnr(rgb, rgb_ref) > 56.0 and float((err > 1e-2).float().mean()) < 0.005
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "f16x3"])
+def test_rays_missing_the_sphere_render_nan(gpu_modules, dtype):
+    """The reference does not clamp sqrt of a negative discriminant (utils.py:159-217): a ray that misses the DepthNet's
+    sphere gets a NaN depth, NaN sample points and -- through sin/cos, nn.Linear and relu -- a NaN pixel.  Every operand
+    type reproduces that, for exactly the rays the oracle does it for."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("tiny_synth")
+    p = m["params"]
+    o = torch.tensor([[0.0, 0.0, 4.0], [0.0, 0.0, 4.0], [3.0, 0.0, 4.0], [0.1, -0.2, 4.0]])
+    d = torch.tensor([[0.0, 0.0, -1.0], [0.0, 1.0, 0.0], [0.0, 0.0, -1.0], [0.0, 0.05, -1.0]])     # rays 1 and 2 miss r = 2
+    v = torch.nn.functional.normalize(d, dim=-1)
+    batch = torch.cat([o, d, torch.full((4, 1), 2.0), torch.full((4, 1), 6.0), v], -1)
+    ref = O.render_rays_test(batch, p["coarse"], p["fine"], p["depth"], 8, "uniform", 0.1)
+    ref_nan = torch.isnan(ref["depth_net_rgb_map"]).any(-1)
+    assert ref_nan.tolist() == [False, True, True, False]
+    out = ops.render_rays_depthnet(m["depth"].packed(dtype), m["fine"].packed(dtype), rays=(o.cuda(), d.cuda(), v.cuda()),
+                                   n_samples=8, mode="uniform", std=0.1, extras=True)
+    assert torch.isnan(out["rgb"].cpu()).all(-1).tolist() == ref_nan.tolist()
+    assert torch.isnan(out["z"].cpu()).all(-1).tolist() == ref_nan.tolist()
+    assert torch.isfinite(out["rgb"].cpu()[~ref_nan]).all()
