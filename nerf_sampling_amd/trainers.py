@@ -170,6 +170,11 @@ class Trainer:
             if i % self.i_print == 0:
                 print(f"[TRAIN] Iter: {i} Loss: {float(loss)} depth_net_loss: {float(depth_net_loss)} "
                       f"PSNR: {float(psnr)}")
+                # the reference's progress line, appended to {basedir}/{expname}/psnr.txt (Trainer.py:378-392; wandb is
+                # out of scope)
+                info = f"Iter: {i} Loss: {float(loss)}, Depth Net Loss: {float(depth_net_loss)}, PSNR: {float(psnr):.5f}"
+                with open(os.path.join(self.basedir, self.expname, "psnr.txt"), "a") as file:
+                    file.write(f"{info}\n")
             if i % self.i_weights == 0:
                 path = os.path.join(self.basedir, self.expname, "{:06d}.tar".format(i))
                 utils.save_state(self.global_step, render_kwargs_train["network_fn"],

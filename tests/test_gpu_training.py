@@ -171,6 +171,8 @@ def test_train_loop_end_to_end(tmp_path, gpu_modules):
     assert psnr is not None and np.isfinite(float(psnr))
     ckpts = sorted(f for f in os.listdir(os.path.join(logs, "exp")) if f.endswith(".tar"))
     assert ckpts == ["000003.tar", "000006.tar"]
+    lines = open(os.path.join(logs, "exp", "psnr.txt")).read().splitlines()      # i_print = 2: iterations 2, 4, 6
+    assert len(lines) == 3 and lines[0].startswith("Iter: 2 Loss: ") and ", Depth Net Loss: " in lines[0] and ", PSNR: " in lines[0]
     ck = torch.load(os.path.join(logs, "exp", "000006.tar"), weights_only=True)
     assert set(ck) == {"global_step", "network_fn_state_dict", "network_fine_state_dict", "optimizer_state_dict",
                        "sampling_optimizer_state_dict", "depth_network"}
