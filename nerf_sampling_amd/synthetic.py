@@ -137,7 +137,46 @@ def make_depthnet_params(
     return p
 
 
+def make_depthnet_params_shaped(seed: int, hidden_sizes, cat_hidden_sizes, multires: int = 10,
+                                branch_gain: float = 1.0, trunk_gain: float = 1.0) -> Params:
+    """make_depthnet_params for arbitrary branch widths (``hidden_sizes``) and trunk widths (``cat_hidden_sizes``), the
+    shapes depth_net.py:46-101 builds: branch layer i is [hidden[i], (hidden[i-1] | e) + e], trunk layer 0 is
+    [cat[0], 3 hidden[-1] + 2 e3 + e6].  Embedding columns of level L are scaled by 2^-L as in the scenes."""
+    rng = np.random.default_rng(seed)
+    e3, e6 = posenc_dim(3, multires), posenc_dim(6, multires)
+    hs, cs = list(hidden_sizes), list(cat_hidden_sizes)
+    p: Params = {}
+    for prefix, e in (("origin_layers", e3), ("direction_layers", e3), ("intersection_layers", e6)):
+        for i, out_f in enumerate(hs):
+            prev = e if i == 0 else hs[i - 1]
+            w, b = _uniform_linear(rng, out_f, prev + e, branch_gain)
+            dch = 3 if e == e3 else 6
+            if i == 0:
+                _decay_embedding_columns(w, 0, dch, multires)
+            _decay_embedding_columns(w, prev, dch, multires)
+            p[f"{prefix}.{i}.weight"], p[f"{prefix}.{i}.bias"] = w, b
+    for i, out_f in enumerate(cs):
+        in_f = 3 * hs[-1] + 2 * e3 + e6 if i == 0 else cs[i - 1]
+        w, b = _uniform_linear(rng, out_f, in_f, trunk_gain)
+        if i == 0:
+            _decay_embedding_columns(w, 3 * hs[-1], 3, multires)
+            _decay_embedding_columns(w, 3 * hs[-1] + e3, 3, multires)
+            _decay_embedding_columns(w, 3 * hs[-1] + 2 * e3, 6, multires)
+        p[f"cat_layers.{2 * i}.weight"], p[f"cat_layers.{2 * i}.bias"] = w, b
+    w, b = _uniform_linear(rng, 1, cs[-1], trunk_gain)
+    p["to_depth.0.weight"], p["to_depth.0.bias"] = w, b
+    return p
+
+
 SQRT3, SQRT6 = math.sqrt(3.0), math.sqrt(6.0)
+
+# DepthNet shapes other than one uniform width, pinned against the reference by tests/golden/depthnet_shapes.npz:
+# tag -> (hidden_sizes, cat_hidden_sizes, seed).  "default" is the reference's class default (depth_net.py:13-16).
+DEPTHNET_SHAPES = {
+    "default": ([128] * 6, [128, 128, 128, 128, 256], 71),
+    "ragged": ([48, 80], [64, 16, 200, 256], 72),
+    "one": ([32], [96], 73),
+}
 
 # Canonical synthetic "scenes": seeds and density-head calibration chosen once so that a
 # frame has a mix of opaque / transparent rays (probe: tools/make_golden.py --stats).

@@ -423,3 +423,30 @@ def test_nerf_mlp_nan_points_stay_nan(ops, gpu_modules, dtype):
     assert torch.isnan(raw[1, 2]).all(), raw[1, 2]
     ok = torch.ones(3, 5, dtype=torch.bool); ok[1, 2] = False
     assert torch.isfinite(raw[ok]).all()
+
+
+@pytest.mark.parametrize("tag", ["default", "ragged", "one"])
+def test_depthnet_shapes_golden(ops, golden, tag):
+    """The same non-uniform DepthNet shapes through the folded HIP kernels against outputs captured from the REFERENCE
+    (tests/golden/depthnet_shapes.npz): fp32 and f16x3 at the fp32 gate, bf16 / f16 at 3x their measured error."""
+    from nerf_sampling_amd import synthetic
+    from nerf_sampling_amd.depth_net import DepthNet
+
+    g = golden("depthnet_shapes")
+    hs, cs, seed = synthetic.DEPTHNET_SHAPES[tag]
+    dn = DepthNet(hidden_sizes=list(hs), cat_hidden_sizes=list(cs))
+    dn.load_state_dict(synthetic.make_depthnet_params_shaped(seed, hs, cs, branch_gain=synthetic.SQRT3,
+                                                             trunk_gain=synthetic.SQRT6))
+    dn = dn.cuda()
+    for q in dn.parameters():
+        q.requires_grad_(False)
+    exp = g[f"z_{tag}"]
+    ok = ~np.isnan(exp[:, 0])
+    # measured max |z err| (round 2): f32 1.7e-6, f16x3 1.2e-6, f16 1.3e-3, bf16 8.8e-3
+    for dtype, tol in (("f32", 2e-4), ("f16x3", 2e-4), ("f16", 4e-3), ("bf16", 2.6e-2)):
+        z = ops.depthnet_forward(dn.packed(dtype), dev(g["o"]), dev(g["d"])).cpu().numpy()
+        assert z.shape == exp.shape
+        assert np.isnan(z[~ok]).all(), dtype                                   # rays that miss the sphere stay NaN
+        err = np.abs(z - exp)[ok]
+        print(f"depthnet_shapes {tag} {dtype}: max |z err| {err.max():.3e}")
+        assert err.max() < tol, (tag, dtype, float(err.max()))

@@ -109,6 +109,26 @@ def test_depthnet(golden, scenes, scene):
     close(z, exp, 1e-6, 1e-6)
 
 
+@pytest.mark.parametrize("tag", ["default", "ragged", "one"])
+def test_depthnet_shapes(golden, tag):
+    """Branch / trunk widths other than one uniform value -- the reference's class defaults (depth_net.py:13-16, the shapes
+    its own structure tests build, tests.py:115-194) and two ragged ones -- against outputs captured from the reference."""
+    from nerf_sampling_amd import synthetic
+
+    g = golden("depthnet_shapes")
+    hs, cs, seed = synthetic.DEPTHNET_SHAPES[tag]
+    p = synthetic.make_depthnet_params_shaped(seed, hs, cs, branch_gain=synthetic.SQRT3, trunk_gain=synthetic.SQRT6)
+    if tag == "default":      # structure of the class defaults, tests.py:115-194
+        assert p["origin_layers.0.weight"].shape == (128, 126) and p["intersection_layers.5.weight"].shape == (128, 254)
+        assert p["cat_layers.0.weight"].shape == (128, 3 * 128 + 252) and p["cat_layers.8.weight"].shape == (256, 128)
+        assert p["to_depth.0.weight"].shape == (1, 256)
+    z = O.depthnet_forward(p, T(g["o"]), T(g["d"]))
+    exp = g[f"z_{tag}"]
+    assert z.shape == exp.shape == (96, 1)
+    assert np.isnan(exp[94:96]).all() and exp[:94].std() > 0.05
+    close(z, exp, 1e-6, 1e-6)
+
+
 def test_depthnet_structure():
     """Layer structure pinned by tests.py:115-194 (dims of the production configuration)."""
     p = O.make_depthnet_params(0, n_layers=10, width=256)

@@ -324,6 +324,25 @@ def main():
                 out[f"{n}_{k}"] = v
         save("render_rays_train", **out)
 
+        # ---- a4 DepthNet shapes other than one uniform width (appended LAST and on its own generator, so that every
+        #      fixture above keeps its random stream): the class defaults of depth_net.py:13-16 and two ragged shapes
+        print("a4 depthnet shapes")
+        from nerf_sampling_amd import synthetic
+
+        g2 = torch.Generator().manual_seed(4321)
+        o_s = torch.nn.functional.normalize(torch.randn(94, 3, generator=g2), dim=-1) * 4.03
+        d_s = torch.nn.functional.normalize(-o_s + 0.3 * torch.randn(94, 3, generator=g2), dim=-1)
+        o_s = torch.cat([o_s, torch.tensor([[0., 0, 4.0], [3., 3, 3]])])
+        d_s = torch.cat([d_s, torch.tensor([[1., 0, 0], [0., 0, 1]])])        # two rays that miss the sphere: NaN
+        out = {"o": o_s, "d": d_s}
+        for tag, (hs, cs, seed) in synthetic.DEPTHNET_SHAPES.items():
+            params = synthetic.make_depthnet_params_shaped(seed, hs, cs, branch_gain=synthetic.SQRT3,
+                                                           trunk_gain=synthetic.SQRT6)
+            net = quiet(ref.depth_net.DepthNet, hidden_sizes=list(hs), cat_hidden_sizes=list(cs), sphere_radius=2.0)
+            net.load_state_dict(params)
+            out[f"z_{tag}"] = net.eval()(o_s, d_s)
+        save("depthnet_shapes", **out)
+
     if "--stats" in sys.argv:
         w = out  # noqa
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
