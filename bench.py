@@ -222,7 +222,9 @@ def api_path_rate(fine, dn, params, scene, dtype, H, W, K, poses, n_samples, dev
                          input_dims_embed=3, device="cuda", n_depth_samples=n_samples, sampling_mode="uniform", distance=0.1)
     embed_fn, _ = get_embedder(tr.multires, tr.i_embed, 3)
     embeddirs_fn, _ = get_embedder(tr.multires_views, tr.i_embed, 3)
-    query = lambda i_, v_, f_: tr.run_network(i_, v_, f_, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=tr.netchunk)  # noqa: E731
+    # the query function exactly as nerf_utils.create_nerf builds (and tags) it for a user of the mirrored API
+    query = nerf_utils.standard_query_fn(
+        lambda i_, v_, f_: tr.run_network(i_, v_, f_, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=tr.netchunk))
     kw = dict(network_query_fn=query, perturb=0.0, N_importance=128, network_fine=fine, N_samples=64, network_fn=fine,
               use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, trainer=tr, lindisp=True, depth_network=dn,
               model_mode="test", near=2.0, far=6.0, ndc=False, _blocking_host_copies=blocking)

@@ -29,7 +29,7 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @click.option("-sr", "--single_ray", is_flag=True, default=False, help="Train sampling network on single ray.")
 @click.option("-ip", "--i_print", default=1000, help="Frequency of log printing.", show_default=True)
 @click.option("--iters", default=100_000, show_default=True, help="Training iterations (EPOCHS in the reference).")
-@click.option("--dtype", default="f32", type=click.Choice(["bf16", "f16", "f32"]), show_default=True,
+@click.option("--dtype", default="f32", type=click.Choice(["bf16", "f16", "f32", "f16x3"]), show_default=True,
               help="MFMA operand precision of the frozen-NeRF forward kernels (not in the reference).")
 @click.option("--root", default=os.getcwd(), show_default=True, help="Directory holding dataset/ pretrained/ logs/.")
 def main(**kw):

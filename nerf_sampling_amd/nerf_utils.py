@@ -216,6 +216,10 @@ def create_nerf(args, model):
         grad_vars += list(model_fine.parameters())
     network_query_fn = lambda inputs, viewdirs, network_fn: args.run_network(  # noqa: E731
         inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
+    if (isinstance(embed_fn, run_nerf_helpers.Embedder) and isinstance(embeddirs_fn, run_nerf_helpers.Embedder)
+            and embed_fn.num_freqs == 10 and embeddirs_fn.num_freqs == 4 and embed_fn.input_dims == 3
+            and embeddirs_fn.input_dims == 3):
+        standard_query_fn(network_query_fn)
     optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
     start = 0
     ckpts = []
@@ -294,6 +298,25 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, trainer, ret
     return ret
 
 
+def standard_query_fn(fn):
+    """Mark a network_query_fn as the standard one (embed + Trainer.run_network through this package's 10 / 4-frequency
+    embedders, exactly what create_nerf builds): render_rays_test may then run its DepthNet branch as one fused C call."""
+    fn._ns_standard_query = True
+    return fn
+
+
+def _one_call_eligible(depth_network, net, network_query_fn, trainer, viewdirs) -> bool:
+    from .depth_net import DepthNet
+    from .trainers import DepthNetTrainer
+
+    return (viewdirs is not None and getattr(network_query_fn, "_ns_standard_query", False)
+            and isinstance(depth_network, DepthNet) and isinstance(net, run_nerf_helpers.NeRF)
+            and type(trainer).raw2outputs is DepthNetTrainer.raw2outputs
+            and type(trainer).run_network is DepthNetTrainer.run_network
+            and trainer.sampling_mode in ("uniform", "gaussian", "depth_only")
+            and not (torch.is_grad_enabled() and any(p.requires_grad for p in depth_network.parameters())))
+
+
 def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer, retraw=True, lindisp=False,
                      perturb=0.0, N_importance=0, network_fine=None, white_bkgd=False, raw_noise_std=0.0,
                      verbose=False, pytest=False, **kwargs):
@@ -319,6 +342,18 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
         weights, pts, z_vals = max_weights, max_pts, max_z_vals
     elif trainer.use_full_nerf:
         rgb_map, disp_map, weights, pts, z_vals = fine_rgb, fine_disp, fine_w, fine_pts, fine_z
+    elif _one_call_eligible(kwargs.get("depth_network"), network_fine if network_fine is not None else network_fn,
+                            network_query_fn, trainer, viewdirs):
+        # The standard configuration (this package's DepthNet / NeRF modules, the query function create_nerf builds, the
+        # trainer's own raw2outputs): DepthNet -> placement -> MLP -> compositing as ONE C call, bit-identical to the
+        # operator chain below (tests/test_gpu_render.py::test_fused_matches_operator_chain and the tagged-path test).
+        dn = kwargs["depth_network"]
+        net = network_fine if network_fine is not None else network_fn
+        out = ops.render_rays_depthnet(dn.packed(), net.packed(), rays=(rays_o, rays_d, viewdirs),
+                                       n_samples=trainer.n_depth_samples, mode=trainer.sampling_mode, std=trainer.distance,
+                                       near=dn.near, far=dn.far, sphere_radius=float(dn.sphere_radius.reshape(-1)[0]),
+                                       white_bkgd=True, extras=True, device=rays_o.device)
+        rgb_map, disp_map, weights, pts, z_vals = out["rgb"], out["disp"], out["weights"], out["pts"], out["z"]
     else:
         mean = kwargs["depth_network"](rays_o, rays_d)
         pts, z_vals = sample_points_around_mean(rays_o=rays_o, rays_d=rays_d, mean=mean,

@@ -604,3 +604,35 @@ def test_rays_missing_the_sphere_render_nan(gpu_modules, dtype):
     assert torch.isnan(out["rgb"].cpu()).all(-1).tolist() == ref_nan.tolist()
     assert torch.isnan(out["z"].cpu()).all(-1).tolist() == ref_nan.tolist()
     assert torch.isfinite(out["rgb"].cpu()[~ref_nan]).all()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("ns,mode", [(16, "uniform"), (1, "depth_only")])
+def test_standard_configuration_takes_the_one_call_path_bit_exactly(gpu_modules, dtype, ns, mode):
+    """render_rays_test with the query function create_nerf builds (tagged standard) runs its DepthNet branch as ONE C
+    call; an untagged query function runs the operator chain.  Same keys, shapes, placement and bits."""
+    from nerf_sampling_amd import nerf_utils, ops
+
+    ops.set_compute_dtype(dtype)
+    m = gpu_modules("tiny_synth")
+    tr = make_trainer(n_depth_samples=ns, sampling_mode=mode, distance=0.1)
+    kw = render_kwargs(tr, m)
+    kw.update(near=2.0, far=6.0, ndc=False)
+    H, W = 19, 23
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(-50.0, -30.0, 4.0)[:3, :4]
+    chain = nerf_utils.render_test(H, W, K, chunk=150, c2w=c2w, **kw)
+    calls = []
+    orig = ops.render_rays_depthnet
+    ops.render_rays_depthnet = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        kw2 = dict(kw, network_query_fn=nerf_utils.standard_query_fn(lambda i, v, f: kw["network_query_fn"](i, v, f)))
+        fused = nerf_utils.render_test(H, W, K, chunk=150, c2w=c2w, **kw2)
+    finally:
+        ops.render_rays_depthnet = orig
+    assert len(calls) == 3                                        # 437 rays in chunks of 150
+    assert torch.equal(chain[0], fused[0]) and torch.equal(chain[1].cpu(), fused[1].cpu())
+    assert set(chain[2]) == set(fused[2])
+    for k in chain[2]:
+        assert chain[2][k].shape == fused[2][k].shape and chain[2][k].is_cuda == fused[2][k].is_cuda, k
+        assert torch.equal(chain[2][k].cpu(), fused[2][k].cpu()), k

@@ -23,10 +23,12 @@ kw = dict(network_query_fn=q, perturb=0.0, N_importance=128, network_fine=fine, 
           white_bkgd=True, raw_noise_std=0.0, trainer=tr, lindisp=True, depth_network=dn, model_mode="test", near=2.0, far=6.0,
           ndc=False)
 with torch.no_grad():
-    for blocking in (False, True):
+    for label, blocking, tagged in (("async, one-call branch (create_nerf's query fn)", False, True), ("async, operator chain", False, False),
+                                    ("blocking, operator chain (as the reference)", True, False)):
+        kw["network_query_fn"] = nerf_utils.standard_query_fn(lambda i, v, f: q(i, v, f)) if tagged else q
         ts = []
         for i in range(10):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             rgb, disp, ex = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], _blocking_host_copies=blocking, **kw)
             torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
-        print("blocking" if blocking else "async   ", " ".join(f"{t:6.1f}" for t in ts))
+        print(f"{label:48s}", " ".join(f"{t:6.1f}" for t in ts))
