@@ -1,7 +1,7 @@
 """Import the read-only reference (/root/reference) in THIS container only.
 
-Used by tools/make_golden.py to capture golden vectors.  Never shipped to the GPU box
-(`tools/` is in .gpurunignore) and never imported by the product, tests or bench.
+Used by tools/make_golden.py to capture golden vectors.  Useless on the GPU box (/root/reference does not exist
+there) and never imported by the product, tests or bench.
 
 The reference's hot-path modules import four arithmetic-free packages that are not
 installed here (imageio, cv2, wandb, optuna) at module level; empty stand-in modules are
