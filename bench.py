@@ -173,7 +173,8 @@ SIGMA_NOISE_FRAC = {"bf16": 1.55e-2, "f16": 2.4e-3, "f32": 1.0e-5, "f16x3": 1.0e
 
 
 def accuracy_vs_oracle(ops, depth_w, nerf_w, ref, H, W, K, c2w, n_samples, dtype, device):
-    """PSNR(build || oracle) on the band the CPU leg rendered.  The reference composites the last sample with
+    """Second half of the cpu_baseline leg (the oracle as CHECKER, outside the timed region, rank 0 at N = 1 only):
+    PSNR(build || oracle) on the band the CPU leg rendered.  The reference composites the last sample with
     dist = 1e10 (sampling_trainer.py:176-180): alpha_last = step(sigma_last), so a ray's colour is discontinuous in
     sigma_last; rays whose ORACLE colour moves by > 1e-2 under a sigma shift of 3x the dtype's measured sigma noise are
     ill-conditioned and reported as a fraction; the PSNR is quoted on all rays and on the well-conditioned ones."""
