@@ -72,7 +72,8 @@ def spawn_ranks(n: int) -> int:
         time.sleep(0.05)
     out0 = procs[0].stdout.read() if procs[0].stdout else ""
     rcs = [p_.wait() for p_ in procs]
-    sys.stdout.write(out0 or "")
+    for line in (out0 or "").splitlines():          # the JSON line to stdout, library chatter (gloo prints there) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if failed or any(rcs):
         sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
