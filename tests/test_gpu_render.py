@@ -636,3 +636,27 @@ def test_standard_configuration_takes_the_one_call_path_bit_exactly(gpu_modules,
     for k in chain[2]:
         assert chain[2][k].shape == fused[2][k].shape and chain[2][k].is_cuda == fused[2][k].is_cuda, k
         assert torch.equal(chain[2][k].cpu(), fused[2][k].cpu()), k
+
+
+@pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
+def test_gaussian_mode_with_injected_noise_vs_oracle(gpu_modules, scene):
+    """sampling_mode = "gaussian" (the -e sweep's second mode, utils.py:226-231): the same standard-normal draws injected
+    on both sides; one-call path vs the oracle's render_rays_test, fp32 gate."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules(scene)
+    p = m["params"]
+    H = W = 24
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(123.0, -30.0, 4.0)[:3, :4]
+    batch, o, d, _ = O.ray_batch_from_camera(H, W, K, c2w, 2.0, 6.0)
+    noise = torch.randn(H * W, 31, generator=torch.Generator().manual_seed(9))
+    ref = O.render_rays_test(batch, p["coarse"], p["fine"], p["depth"], 32, "gaussian", 0.05, noise=noise)
+    out = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
+                                   rays=(o.cuda(), d.cuda(), batch[:, -3:].cuda()), n_samples=32, mode="gaussian", std=0.05,
+                                   noise=noise.cuda(), extras=True)
+    assert torch.allclose(out["z"].cpu(), ref["depth_net_z_vals"], rtol=0, atol=3e-4)
+    bad, err = frac_bad(npy(out["rgb"]), ref["depth_net_rgb_map"].numpy(), 2e-4)
+    assert bad <= 0.03 and np.median(err) < 5e-5, (bad, float(np.median(err)))
+    bad, err = frac_bad(npy(out["weights"]), ref["depth_net_weights"].numpy(), 2e-4)
+    assert bad <= 0.03, bad
