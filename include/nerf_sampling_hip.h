@@ -137,6 +137,14 @@ int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d
                    const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
                    float* disp_dev, float* acc_dev, float* depth_dev, float* alphas_dev,
                    float* weights_dev, void* stream);
+/* the same with the per-ray rgb / disp outputs at caller-chosen strides (in floats; rgb of ray r at
+ * rgb_dev + r*rgb_stride, >= 3; disp at disp_dev + r*disp_stride, >= 1): lets a renderer write straight
+ * into an interleaved [R,4] = (r,g,b,disp) frame shard, the unit the multi-GPU all-gather moves
+ * (no reference counterpart: the reference returns separate tensors and has no multi-GPU path)      */
+int ns_raw2outputs_strided(const float* raw_dev, const float* z_dev, const float* rays_d_dev,
+                           const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
+                           int64_t rgb_stride, float* disp_dev, int64_t disp_stride, float* acc_dev,
+                           float* depth_dev, float* alphas_dev, float* weights_dev, void* stream);
 
 /* ---- a11 vanilla hierarchical pieces (Trainer.py:579-710, run_nerf_helpers.py:250-293) ------ */
 /* stratified coarse depths: near/far [R]; t_rand [R,N] uniform draws or NULL (perturb==0)    */
@@ -195,6 +203,10 @@ typedef struct ns_render_args {
    * (the dominant kernel), so a harness can time it inside its own timed region; NULL = none   */
   void* ev_mlp_begin;
   void* ev_mlp_end;
+  /* strides (in floats) of the rgb / disp outputs; 0 = packed (3 / 1).  rgb_stride = disp_stride = 4 with
+   * disp_dev = rgb_dev + 3 writes an interleaved [R,4] shard directly                                  */
+  int64_t rgb_stride;
+  int64_t disp_stride;
 } ns_render_args;
 int64_t ns_render_workspace_bytes(int64_t R, int N);
 int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
@@ -227,6 +239,8 @@ typedef struct ns_hier_args {
   float* raw_dev;
   void* ev_mlp_begin; /* optional hipEvent_t pair around the FINE-pass MLP kernel */
   void* ev_mlp_end;
+  int64_t rgb_stride; /* as in ns_render_args; 0 = packed */
+  int64_t disp_stride;
 } ns_hier_args;
 int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf);
 int ns_render_rays_hierarchical(const ns_hier_args* args, void* stream);

@@ -37,6 +37,7 @@ class RenderArgs(C.Structure):
         ("workspace_dev", _p),
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("pts_dev", _p),
         ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
+        ("rgb_stride", _i64), ("disp_stride", _i64),
     ]
 
 
@@ -53,6 +54,7 @@ class HierArgs(C.Structure):
         ("t_rand_dev", _p), ("u_dev", _p), ("workspace_dev", _p),
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("raw_dev", _p),
         ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
+        ("rgb_stride", _i64), ("disp_stride", _i64),
     ]
 
 
@@ -77,6 +79,7 @@ SIGNATURES = {
     "ns_nerf_forward": (_i, [_p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "ns_nerf_forward_embedded": (_i, [_p, _p, _i64, _p, _p]),
     "ns_raw2outputs": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "ns_raw2outputs_strided": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p, _i64, _p, _i64, _p, _p, _p, _p, _p]),
     "ns_coarse_z": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "ns_sample_pdf": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),
     "ns_importance_z": (_i, [_p, _p, _i64, _i, _i, _p, _p, _p]),

@@ -21,7 +21,8 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
                    const float* __restrict__ rays_d, const float* __restrict__ noise, int64_t R, int N,
                    int white_bkgd, float* __restrict__ rgb_out, float* __restrict__ disp_out,
                    float* __restrict__ acc_out, float* __restrict__ depth_out,
-                   float* __restrict__ alphas_out, float* __restrict__ weights_out) {
+                   float* __restrict__ alphas_out, float* __restrict__ weights_out, int64_t rgb_stride,
+                   int64_t disp_stride) {
   constexpr int RAYS_PER_BLOCK = 256 / SW;
   const int sub = threadIdx.x % SW;
   const int64_t ray_stride = (int64_t)gridDim.x * RAYS_PER_BLOCK;
@@ -61,10 +62,10 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
       nscomp::composite_finish<SW>(A, white_bkgd, disp);
       if (cur.live && sub == 0) {
         const int64_t r = cur.r;
-        if (rgb_out) { rgb_out[r * 3] = A.r; rgb_out[r * 3 + 1] = A.g; rgb_out[r * 3 + 2] = A.b; }
+        if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = A.r; p[1] = A.g; p[2] = A.b; }
         if (acc_out) acc_out[r] = A.acc;
         if (depth_out) depth_out[r] = A.depth;
-        if (disp_out) disp_out[r] = disp;
+        if (disp_out) disp_out[r * disp_stride] = disp;
       }
       cur = nxt;
     }
@@ -99,10 +100,10 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
     float disp;
     nscomp::composite_finish<SW>(A, white_bkgd, disp);
     if (live && sub == 0) {
-      if (rgb_out) { rgb_out[r * 3] = A.r; rgb_out[r * 3 + 1] = A.g; rgb_out[r * 3 + 2] = A.b; }
+      if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = A.r; p[1] = A.g; p[2] = A.b; }
       if (acc_out) acc_out[r] = A.acc;
       if (depth_out) depth_out[r] = A.depth;
-      if (disp_out) disp_out[r] = disp;
+      if (disp_out) disp_out[r * disp_stride] = disp;
     }
   }
 }
@@ -114,15 +115,16 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
 __global__ void __launch_bounds__(256)
 raw2outputs_single_kernel(const float4* __restrict__ raw, int64_t R, float* __restrict__ rgb_out,
                           float* __restrict__ disp_out, float* __restrict__ acc_out,
-                          float* __restrict__ depth_out) {
+                          float* __restrict__ depth_out, int64_t rgb_stride, int64_t disp_stride) {
   for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
     const float4 q = raw[r];
     if (rgb_out) {
-      rgb_out[r * 3] = 1.0f / (1.0f + expf(-q.x));
-      rgb_out[r * 3 + 1] = 1.0f / (1.0f + expf(-q.y));
-      rgb_out[r * 3 + 2] = 1.0f / (1.0f + expf(-q.z));
+      float* p = rgb_out + r * rgb_stride;
+      p[0] = 1.0f / (1.0f + expf(-q.x));
+      p[1] = 1.0f / (1.0f + expf(-q.y));
+      p[2] = 1.0f / (1.0f + expf(-q.z));
     }
-    if (disp_out) disp_out[r] = 1.0f / 1e-10f;
+    if (disp_out) disp_out[r * disp_stride] = 1.0f / 1e-10f;
     if (acc_out) acc_out[r] = 0.0f;
     if (depth_out) depth_out[r] = 0.0f;
   }
@@ -358,13 +360,13 @@ argmax_gather_kernel(const float* __restrict__ w, const float* __restrict__ z, c
 template <int SW>
 void launch_r2o(const float* raw, const float* z, const float* rays_d, const float* noise, int64_t R, int N,
                 int white, float* rgb, float* disp, float* acc, float* depth, float* alphas, float* weights,
-                hipStream_t s) {
+                int64_t rgb_stride, int64_t disp_stride, hipStream_t s) {
   const int rays_per_block = 256 / SW;
   int64_t grid = ns::cdiv(R, rays_per_block);
   if (grid > 256 * 16) grid = 256 * 16;
   raw2outputs_kernel<SW><<<static_cast<int>(grid), 256, 0, s>>>(reinterpret_cast<const float4*>(raw), z, rays_d,
                                                                noise, R, N, white, rgb, disp, acc, depth,
-                                                               alphas, weights);
+                                                               alphas, weights, rgb_stride, disp_stride);
 }
 
 }  // namespace
@@ -375,17 +377,27 @@ int ns_raw2outputs(const float* raw_dev, const float* z_dev, const float* rays_d
                    const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
                    float* disp_dev, float* acc_dev, float* depth_dev, float* alphas_dev,
                    float* weights_dev, void* stream) {
+  return ns_raw2outputs_strided(raw_dev, z_dev, rays_d_dev, noise_dev, R, N, white_bkgd, rgb_dev, 3, disp_dev, 1,
+                                acc_dev, depth_dev, alphas_dev, weights_dev, stream);
+}
+
+int ns_raw2outputs_strided(const float* raw_dev, const float* z_dev, const float* rays_d_dev,
+                           const float* noise_dev, int64_t R, int N, int white_bkgd, float* rgb_dev,
+                           int64_t rgb_stride, float* disp_dev, int64_t disp_stride, float* acc_dev,
+                           float* depth_dev, float* alphas_dev, float* weights_dev, void* stream) {
   NS_REQUIRE(R >= 0 && N >= 1, "bad shape (N == 0 is handled by the caller)");
+  NS_REQUIRE(rgb_stride >= 3 && disp_stride >= 1, "output strides (in floats) must be >= 3 for rgb and >= 1 for disp");
   if (R == 0) return NS_OK;
   NS_REQUIRE(raw_dev && z_dev && rays_d_dev, "null input");
   NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
   hipStream_t s = ns::as_stream(stream);
 #define NS_R2O(SW) launch_r2o<SW>(raw_dev, z_dev, rays_d_dev, noise_dev, R, N, white_bkgd, rgb_dev, disp_dev, \
-                                  acc_dev, depth_dev, alphas_dev, weights_dev, s)
+                                  acc_dev, depth_dev, alphas_dev, weights_dev, rgb_stride, disp_stride, s)
   if (N == 1) {
     // alphas / weights are [R, 0] in the reference for a single sample: nothing to write there
     raw2outputs_single_kernel<<<ns::ew_grid(R, 256), 256, 0, s>>>(reinterpret_cast<const float4*>(raw_dev), R,
-                                                                  rgb_dev, disp_dev, acc_dev, depth_dev);
+                                                                  rgb_dev, disp_dev, acc_dev, depth_dev, rgb_stride,
+                                                                  disp_stride);
   } else if (N <= 2) NS_R2O(2);
   else if (N <= 4) NS_R2O(4);
   else if (N <= 8) NS_R2O(8);

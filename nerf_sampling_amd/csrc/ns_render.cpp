@@ -76,8 +76,9 @@ int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   rc = ns_nerf_forward(a->nerf, nullptr, o, d, z, view, R, N, raw, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
-  return ns_raw2outputs(raw, z, d, nullptr, R, N, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr, nullptr,
-                        a->weights_dev, stream);
+  return ns_raw2outputs_strided(raw, z, d, nullptr, R, N, a->white_bkgd, a->rgb_dev, a->rgb_stride ? a->rgb_stride : 3,
+                                a->disp_dev, a->disp_stride ? a->disp_stride : 1, nullptr, nullptr, nullptr,
+                                a->weights_dev, stream);
 }
 
 int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf) {
@@ -126,8 +127,9 @@ int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
                       stream);
   if (rc != NS_OK) return rc;
   if (a->Nf == 0) {  // no importance samples: the coarse pass is the result
-    return ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr,
-                          nullptr, a->weights_dev, stream);
+    return ns_raw2outputs_strided(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, a->rgb_dev,
+                                  a->rgb_stride ? a->rgb_stride : 3, a->disp_dev, a->disp_stride ? a->disp_stride : 1,
+                                  nullptr, nullptr, nullptr, a->weights_dev, stream);
   }
   // fine pass (Trainer.py:651-710)
   float* z_f = a->z_dev ? a->z_dev : z_f_ws;
@@ -138,8 +140,9 @@ int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   rc = ns_nerf_forward(a->fine ? a->fine : a->coarse, nullptr, o, d, z_f, view, R, Nt, raw_f, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
-  return ns_raw2outputs(raw_f, z_f, d, nullptr, R, Nt, a->white_bkgd, a->rgb_dev, a->disp_dev, nullptr, nullptr, nullptr,
-                        a->weights_dev, stream);
+  return ns_raw2outputs_strided(raw_f, z_f, d, nullptr, R, Nt, a->white_bkgd, a->rgb_dev,
+                                a->rgb_stride ? a->rgb_stride : 3, a->disp_dev, a->disp_stride ? a->disp_stride : 1,
+                                nullptr, nullptr, nullptr, a->weights_dev, stream);
 }
 
 int ns_event_create(void** ev) {

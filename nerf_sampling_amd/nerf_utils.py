@@ -72,9 +72,26 @@ class _HostSink:
         self.keep.clear()
 
 
+_pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
+
+
+def drain_host_copies():
+    """Wait for the host copies of every frame rendered with ``_defer_host_sync=True``; their host tensors are valid
+    afterwards.  render_path calls this before it reads a frame's host tensors and when it is done."""
+    for sink in _pending_sinks:
+        sink.finish()
+    _pending_sinks.clear()
+
+
 def _batchify(render_fn, rays_flat, chunk, **kwargs):
+    """Chunked calls + concatenation (nerf_utils.py:58-85).  Host outputs of render_rays_test land asynchronously in
+    frame-sized pinned buffers (_HostSink).  By default the copies are complete when this returns, as with the
+    reference's blocking `.cpu()` calls.  With ``_defer_host_sync=True`` (render_path's own loop) the tail of frame i's
+    copies stays in flight under frame i+1's kernels: frame i-1 is drained here, frame i by drain_host_copies() or by
+    the next frame."""
     all_returned = {}
     sink = None
+    defer = bool(kwargs.pop("_defer_host_sync", False))
     if render_fn is render_rays_test and rays_flat.is_cuda and not kwargs.get("_blocking_host_copies", False):
         sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device)
     for i in range(0, rays_flat.shape[0], chunk):
@@ -84,7 +101,11 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
         if sink is not None:
             sink.advance(min(chunk, rays_flat.shape[0] - i))
     if sink is not None:
-        sink.finish()
+        if defer:
+            drain_host_copies()          # the previous frame: long finished by now
+            _pending_sinks.append(sink)
+        else:
+            sink.finish()
     return {key: (sink.bufs[key] if sink is not None and key in sink.bufs else torch.cat(all_returned[key], 0))
             for key in all_returned}
 
@@ -162,13 +183,16 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
     total_psnr, total_mse, psnr_info = 0, 0, None
     n_render_poses = render_poses.shape[0]
     for i, c2w in enumerate(render_poses):
-        rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **render_kwargs)
+        # the host copies of frame i stay in flight under frame i+1's kernels (SURVEY 8f-1 "asynchronous D2H of frames");
+        # they are drained before this loop reads them
+        rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], _defer_host_sync=True, **render_kwargs)
         rgbs.append(rgb.cpu().numpy())
         disps.append(disp.cpu().numpy())
         if gt_imgs is not None and render_factor == 0:
             psnr = -10.0 * np.log10(np.mean(np.square(rgbs[-1] - np.asarray(gt_imgs[i]))))
             psnr_info = f"{i:03d}.png, PSNR: {psnr}"
             if render_kwargs["trainer"].compare_nerf and extras.get("max_z_vals") is not None:
+                drain_host_copies()
                 mse = torch.nn.functional.mse_loss(extras["max_z_vals"], extras["depth_net_z_vals"])
                 total_mse += mse
                 psnr_info += f", MSE: {mse}"
@@ -188,8 +212,13 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
                     with open(f, "a") as file:
                         file.write(to_write)
             if save_scene_data:
-                all_pts.append(torch.flatten(extras["depth_net_pts"], end_dim=2))
-                all_weights.append(torch.flatten(extras["depth_net_weights"], end_dim=2))
+                # pageable copies: the frame's pinned buffers go back to the allocator's cache instead of piling up
+                # (0.7 GB of page-locked memory per 800x800 frame otherwise)
+                drain_host_copies()
+                for dst, key in ((all_pts, "depth_net_pts"), (all_weights, "depth_net_weights")):
+                    flat = torch.flatten(extras[key], end_dim=2)
+                    dst.append(torch.empty(flat.shape, dtype=flat.dtype, device="cpu", pin_memory=False).copy_(flat))
+    drain_host_copies()
     if save_scene_data and savedir is not None:
         torch.save({"all_pts": torch.cat(all_pts), "all_weights": torch.cat(all_weights)},
                    os.path.join(savedir, "scene_data.pt"))

@@ -357,15 +357,32 @@ class RenderWorkspace:
 _default_ws = RenderWorkspace()
 
 
+def _rgb_disp_outputs(a, R: int, device, shard: Optional[Tensor]):
+    """Per-ray outputs of the one-call renderers: fresh packed tensors, or views of an interleaved [.., 4] shard."""
+    if shard is None:
+        out = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=device),
+               "disp": torch.empty((R,), dtype=torch.float32, device=device)}
+        a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
+        return out
+    if not (shard.is_cuda and shard.dtype == torch.float32 and shard.dim() == 2 and shard.shape[1] == 4
+            and shard.is_contiguous() and shard.shape[0] >= R):
+        raise ValueError(f"shard must be a contiguous fp32 device tensor [>= {R}, 4], got {tuple(shard.shape)} {shard.dtype}")
+    a.rgb_dev, a.disp_dev = shard.data_ptr(), shard.data_ptr() + 12
+    a.rgb_stride = a.disp_stride = 4
+    return {"rgb": shard[:R, :3], "disp": shard[:R, 3]}
+
+
 def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=None, camera=None,
                          n_samples: int, mode: str, std: float, noise: Optional[Tensor] = None,
                          near: float = 2.0, far: float = 6.0, sphere_radius: float = 2.0,
                          white_bkgd: bool = True, extras: bool = False, workspace: Optional[RenderWorkspace] = None,
-                         device="cuda", mlp_events=None):
+                         device="cuda", mlp_events=None, shard: Optional[Tensor] = None):
     """DepthNet -> placement -> NeRF MLP -> compositing as one C call.
 
     rays = (o, d, viewdirs) device tensors, or camera = (H, W, K, c2w, row0, row1) to generate
     the rays on the device.  Returns dict(rgb [R,3], disp [R], and with extras z/weights/pts).
+    ``shard``: a contiguous fp32 [>= R, 4] device tensor; the compositing kernel then writes (r, g, b, disp) of ray i
+    straight into shard[i] (the unit parallel.FrameRenderer all-gathers) and rgb / disp are returned as views of it.
     """
     lib = _lib.load()
     a = _lib.RenderArgs()
@@ -407,9 +424,7 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     ws = (workspace or _default_ws).get(nbytes, device)
     base = ws.data_ptr()
     a.workspace_dev = (base + 255) & ~255
-    out = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=device),
-           "disp": torch.empty((R,), dtype=torch.float32, device=device)}
-    a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
+    out = _rgb_disp_outputs(a, R, device, shard)
     if extras:
         out["z"] = torch.empty((R, N), dtype=torch.float32, device=device)
         # one sample: the reference's weights are [R, 0] (its dists are empty) and ns_raw2outputs writes none
@@ -427,8 +442,10 @@ def render_rays_hierarchical(coarse: PackedWeights, fine: Optional[PackedWeights
                              n_coarse: int = 64, n_importance: int = 128, lindisp: bool = True,
                              white_bkgd: bool = True, near: float = 2.0, far: float = 6.0,
                              t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None, extras: bool = False,
-                             workspace: Optional[RenderWorkspace] = None, device="cuda", mlp_events=None):
-    """Vanilla coarse + fine pass (sample_as_in_NeRF) as one C call; returns the FINE pass outputs."""
+                             workspace: Optional[RenderWorkspace] = None, device="cuda", mlp_events=None,
+                             shard: Optional[Tensor] = None):
+    """Vanilla coarse + fine pass (sample_as_in_NeRF) as one C call; returns the FINE pass outputs.
+    ``shard``: as in render_rays_depthnet."""
     lib = _lib.load()
     a = _lib.HierArgs()
     a.coarse = coarse.handle
@@ -461,9 +478,7 @@ def render_rays_hierarchical(coarse: PackedWeights, fine: Optional[PackedWeights
     ws = (workspace or _default_ws).get(nbytes, device)
     a.workspace_dev = (ws.data_ptr() + 255) & ~255
     Nt = a.Nc + a.Nf
-    out = {"rgb": torch.empty((R, 3), dtype=torch.float32, device=device),
-           "disp": torch.empty((R,), dtype=torch.float32, device=device)}
-    a.rgb_dev, a.disp_dev = out["rgb"].data_ptr(), out["disp"].data_ptr()
+    out = _rgb_disp_outputs(a, R, device, shard)
     if extras:
         out["z"] = torch.empty((R, Nt), dtype=torch.float32, device=device)
         out["weights"] = torch.empty((R, Nt), dtype=torch.float32, device=device)

@@ -24,8 +24,11 @@ def row_range(H: int, rank: int, world: int) -> Tuple[int, int, int]:
 class FrameRenderer:
     """Renders full frames, sharded by rows over the ranks of ``group``.
 
-    ``render_rows(c2w, row0, row1) -> (rgb [R,3], disp [R])`` produces this rank's shard; the default
-    is the fused HIP path (ops.render_rays_depthnet) with rays generated on the device.
+    ``render_rows(c2w, row0, row1, shard) -> (rgb [R,3], disp [R])`` produces this rank's shard; the default
+    is the fused HIP path (ops.render_rays_depthnet) with rays generated on the device.  ``shard`` is this
+    rank's interleaved [rows*W, 4] = (r, g, b, disp) buffer, the unit the all-gather moves: a renderer that
+    returns views of it (the HIP renderers write it from the compositing kernel) costs no copy; anything else is
+    copied in.
     """
 
     def __init__(self, H: int, W: int, render_rows: Callable, device, group=None):
@@ -45,9 +48,10 @@ class FrameRenderer:
         """rgb [H,W,3], disp [H,W] of the whole frame, on every rank."""
         n = self.rays_per_rank
         if n > 0:
-            rgb, disp = self.render_rows(c2w, self.row0, self.row1)
-            self.shard[:n, :3] = rgb
-            self.shard[:n, 3] = disp
+            rgb, disp = self.render_rows(c2w, self.row0, self.row1, self.shard)
+            if rgb.data_ptr() != self.shard.data_ptr():          # a renderer that did not write the shard itself
+                self.shard[:n, :3] = rgb
+                self.shard[:n, 3] = disp
         if self.world == 1:
             full = self.shard
         else:
@@ -58,21 +62,27 @@ class FrameRenderer:
 
 
 def hip_row_renderer(depthnet, nerf, H: int, W: int, K, n_samples: int, mode: str, std: float, near: float = 2.0,
-                     far: float = 6.0, sphere_radius: float = 2.0, device="cuda", events: Optional[list] = None):
+                     far: float = 6.0, sphere_radius: float = 2.0, device="cuda", events: Optional[list] = None,
+                     max_events: int = 128):
     """render_rows callable over the fused HIP path.  ``events``: list the (begin, end) hipEvent pair of the
-    NeRF-MLP kernel of each call is appended to (bench.py's live roofline timing)."""
+    NeRF-MLP kernel of each call is appended to (bench.py's live roofline timing; the caller clears the list to
+    start a new measurement).  At most ``max_events`` calls are timed per measurement."""
     from . import ops
 
     ws = ops.RenderWorkspace()
+    ring = []        # hipEvent pairs: all created by the first call, none inside a timed region
 
-    def render_rows(c2w, row0, row1):
+    def render_rows(c2w, row0, row1, shard=None):
         ev = None
         if events is not None:
-            ev = (ops.Event(), ops.Event())
-            events.append(ev)
+            if not ring:
+                ring.extend((ops.Event(), ops.Event()) for _ in range(max_events))
+            if len(events) < max_events:        # frames beyond the ring are rendered untimed
+                ev = ring[len(events)]
+                events.append(ev)
         out = ops.render_rays_depthnet(depthnet, nerf, camera=(H, W, K, c2w, row0, row1), n_samples=n_samples,
                                        mode=mode, std=std, near=near, far=far, sphere_radius=sphere_radius,
-                                       workspace=ws, device=device, mlp_events=ev)
+                                       workspace=ws, device=device, mlp_events=ev, shard=shard)
         return out["rgb"], out["disp"]
 
     return render_rows

@@ -8,6 +8,7 @@ nothing here touches the HIP library or the oracle.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict
 
 import numpy as np
@@ -196,8 +197,33 @@ SCENES = {
 }
 
 
+FITTED_SCENE_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                "fitted_scene")
+
+# "shapes_fit": production-size networks FITTED (tools/fit_scene.py, on an MI355X) to the analytic ground-truth scene of
+# nerf_sampling_amd/analytic_scene.py: one NeRF 8x256 used as both network_fn and network_fine, and the 10x256 DepthNet
+# trained against it with this repo's own training step.  The weights are committed fixtures (safetensors, fp32).
+SCENES["shapes_fit"] = dict(coarse=dict(D=8, W=256), fine=dict(D=8, W=256), depth=dict(n_layers=10, width=256),
+                            files=("nerf.safetensors", "depthnet.safetensors"))
+
+
+def load_fitted_scene(directory: str = None) -> Dict[str, Params]:
+    from safetensors.torch import load_file
+
+    directory = directory or FITTED_SCENE_DIR
+    nerf_file, depth_file = SCENES["shapes_fit"]["files"]
+    for f in (nerf_file, depth_file):
+        if not os.path.exists(os.path.join(directory, f)):
+            raise FileNotFoundError(f"{os.path.join(directory, f)}: the fitted scene's weights are missing "
+                                    "(tools/fit_scene.py writes them)")
+    nerf = load_file(os.path.join(directory, nerf_file))
+    return {"coarse": nerf, "fine": nerf, "depth": load_file(os.path.join(directory, depth_file))}
+
+
 def make_scene(name: str = "lego_synth") -> Dict[str, Params]:
     cfg = SCENES[name]
+    if "files" in cfg:
+        return load_fitted_scene()
     return {
         "coarse": make_nerf_params(**cfg["coarse"]),
         "fine": make_nerf_params(**cfg["fine"]),

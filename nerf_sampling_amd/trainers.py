@@ -1,10 +1,11 @@
 """Mirror of the trainer-side operators the render path calls back into.
 
 Reference: nerf_sampling/nerf_pytorch/trainers/Trainer.py (run_network :789-806,
-sample_coarse_points :579-649, sample_fine_points :651-710, _sample_points :553-577),
-trainers/Blender.py, nerf_sampling/trainers/sampling_trainer.py (DepthNetTrainer.raw2outputs
-:153-230, create_nerf_model :54-122).  Dataset I/O, logging and the optimisation loop are out
-of scope; ``train`` says so loudly.
+sample_coarse_points :579-649, sample_fine_points :651-710, _sample_points :553-577, train :712-787,
+core_optimization_loop :506-544, the two batch samplers :232-269 / :400-475), trainers/Blender.py,
+nerf_sampling/trainers/sampling_trainer.py (DepthNetTrainer.raw2outputs :153-230, create_nerf_model :54-122,
+save_rays_data :124-138).  ``train`` renders (render_only) or runs the DepthNet optimisation loop on the HIP backward
+kernels (autograd.py); wandb / optuna logging and the mp4 writer are out of scope.
 """
 
 from __future__ import annotations

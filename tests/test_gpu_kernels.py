@@ -450,3 +450,47 @@ def test_depthnet_shapes_golden(ops, golden, tag):
         err = np.abs(z - exp)[ok]
         print(f"depthnet_shapes {tag} {dtype}: max |z err| {err.max():.3e}")
         assert err.max() < tol, (tag, dtype, float(err.max()))
+
+
+# ---- the reference's pytest=True determinism hook, through the mirrored API -----------------------------------------
+def test_pytest_hook_against_the_reference(ops, golden, gpu_modules):
+    """pytest=True (Trainer.py:621-624, run_nerf_helpers.py:265-273, sampling_trainer.py:188-193): numpy draws under
+    np.random.seed(0).  Expected values are the reference's own outputs (tests/golden/pytest_hook.npz).  Recorded
+    difference: the reference's numpy draws are float64 and promote everything downstream to float64 (which is also why
+    its sample_as_in_NeRF(pytest=True) raises at the MLP); this build casts the draws to fp32 and stays fp32, so the
+    comparison is at fp32 rounding."""
+    from test_gpu_render import make_trainer, render_kwargs
+
+    from nerf_sampling_amd.run_nerf_helpers import sample_pdf
+
+    g = golden("pytest_hook")
+    # sample_pdf(det=True / False, pytest=True)
+    for det, key in ((True, "pdf_det"), (False, "pdf_rnd")):
+        mine = sample_pdf(dev(g["pdf_bins"]), dev(g["pdf_weights"]), 128, det=det, pytest=True)
+        assert mine.dtype == torch.float32
+        err = np.abs(mine.cpu().numpy() - g[key])
+        assert np.mean(err > 2e-5) < 2e-3 and np.median(err) < 1e-6, (key, float(np.mean(err > 2e-5)))
+    # raw2outputs(raw_noise_std > 0, pytest=True): uniform numpy noise
+    tr = make_trainer()
+    res = tr.raw2outputs(dev(g["r2o_raw"]), dev(g["r2o_z"]), dev(g["r2o_rays_d"]), float(g["r2o_std"]), True, pytest=True)
+    close(res[5], g["r2o_alphas"], 2e-6, 1e-7)
+    close(res[6], g["r2o_weights"], 3e-5, 1e-7)
+    close(res[0], g["r2o_rgb"], 1e-5, 2e-6)
+    close(res[1], g["r2o_disp"], 2e-5, 1e-6)
+    close(res[2], g["r2o_acc"], 1e-5, 1e-6)
+    close(res[3], g["r2o_depth"], 1e-5, 2e-6)
+    close(res[4], g["r2o_density"], 0, 0)
+    # sample_coarse_points(perturb=1, pytest=True): stratified jitter, then the coarse MLP + compositing
+    m = gpu_modules("tiny_synth")
+    kw = render_kwargs(tr, m)
+    rb = dev(g["coarse_ray_batch"])
+    for lindisp in (True, False):
+        out = tr.sample_coarse_points(near=rb[:, 6].contiguous(), far=rb[:, 7].contiguous(), perturb=1.0,
+                                      N_rays=rb.shape[0], N_samples=64, viewdirs=rb[:, -3:].contiguous(),
+                                      network_fn=m["coarse"], network_query_fn=kw["network_query_fn"],
+                                      rays_o=rb[:, 0:3].contiguous(), rays_d=rb[:, 3:6].contiguous(), raw_noise_std=0.0,
+                                      white_bkgd=True, pytest=True, lindisp=lindisp)
+        close(out[5], g[f"coarse_lin{int(lindisp)}_z"], 2e-6, 1e-6)
+        bad, _ = (np.mean(np.abs(out[0].cpu().numpy() - g[f"coarse_lin{int(lindisp)}_rgb_map"]).max(-1) > 1e-4), None)
+        assert bad <= 0.02, bad                          # fp32 MLP at golden-level tolerance, as test_sample_as_in_nerf
+        assert np.median(np.abs(out[3].cpu().numpy() - g[f"coarse_lin{int(lindisp)}_weights"])) < 1e-5

@@ -286,3 +286,48 @@ def test_render_rays_train(golden, scenes, scene):
     res = O.render_rays(T(g["ray_batch"]), sc["coarse"], sc["fine"], sc["depth"], white_bkgd=True)
     for k, v in res.items():
         close(v, g[f"{scene}_{k}"], 5e-5, 5e-5)
+
+
+# ---- the reference's pytest=True determinism hook ------------------------------------------------
+def _np_draws(*shape):
+    """What the reference draws under pytest=True: np.random.seed(0); np.random.rand(*shape) -- float64."""
+    np.random.seed(0)
+    return np.random.rand(*shape)
+
+
+def test_pytest_hook_sample_pdf(golden):
+    """run_nerf_helpers.py:265-273: u = np.linspace / np.random.rand under seed 0, as float64 (the reference's outputs are
+    float64 from there on; the oracle is fed the same draws in fp32, so agreement is to fp32 rounding of u)."""
+    g = golden("pytest_hook")
+    bins, w = T(g["pdf_bins"]), T(g["pdf_weights"])
+    assert g["pdf_det"].dtype == np.float64 and g["pdf_rnd"].dtype == np.float64
+    u_det = torch.tensor(np.broadcast_to(np.linspace(0.0, 1.0, 128), (24, 128)).copy(), dtype=torch.float32)
+    u_rnd = torch.tensor(_np_draws(24, 128), dtype=torch.float32)
+    for u, exp in ((u_det, g["pdf_det"]), (u_rnd, g["pdf_rnd"])):
+        err = np.abs(O.sample_pdf(bins, w, 128, det=False, u=u).numpy() - exp)
+        assert np.mean(err > 2e-5) < 2e-3 and np.median(err) < 1e-6, (float(np.mean(err > 2e-5)), float(np.median(err)))
+
+
+def test_pytest_hook_raw2outputs_noise(golden):
+    """sampling_trainer.py:188-193: noise = np.random.rand(..) * raw_noise_std under seed 0 (uniform, not normal)."""
+    g = golden("pytest_hook")
+    raw, z, rd, std = T(g["r2o_raw"]), T(g["r2o_z"]), T(g["r2o_rays_d"]), float(g["r2o_std"])
+    noise = torch.tensor(_np_draws(*raw.shape[:2]), dtype=torch.float32)
+    res = O.raw2outputs(raw, z, rd, std, True, noise=noise)
+    for nm, v in zip(("rgb", "disp", "acc", "depth", "density", "alphas", "weights"), res):
+        close(v, g[f"r2o_{nm}"], 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("lindisp", [True, False])
+def test_pytest_hook_coarse_jitter(golden, scenes, lindisp):
+    """Trainer.py:612-626 with pytest=True: stratified jitter from np.random.rand under seed 0."""
+    g = golden("pytest_hook")
+    rb = T(g["coarse_ray_batch"])
+    t_rand = torch.tensor(_np_draws(rb.shape[0], 64), dtype=torch.float32)
+    z = O.coarse_z_vals(rb[:, 6:7], rb[:, 7:8], rb.shape[0], 64, lindisp, 1.0, t_rand)
+    close(z, g[f"coarse_lin{int(lindisp)}_z"], 1e-6, 1e-6)
+    sc = scenes("tiny_synth")
+    pts = rb[:, None, 0:3] + rb[:, None, 3:6] * z[..., None]
+    res = O.raw2outputs(O.run_network(sc["coarse"], pts, rb[:, -3:]), z, rb[:, 3:6], 0.0, True)
+    close(res[0], g[f"coarse_lin{int(lindisp)}_rgb_map"], 2e-4, 2e-5)
+    close(res[6], g[f"coarse_lin{int(lindisp)}_weights"], 2e-4, 2e-5)

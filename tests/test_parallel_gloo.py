@@ -33,7 +33,7 @@ def _oracle_rows(H, W):
     sc = O.make_scene("tiny_synth")
     _, K = O.blender_intrinsics(H, W)
 
-    def render_rows(c2w, row0, row1):
+    def render_rows(c2w, row0, row1, shard=None):
         batch, _, _, _ = O.ray_batch_from_camera(H, W, K, c2w, 2.0, 6.0)
         res = O.render_rays_test(batch[row0 * W : row1 * W], sc["coarse"], sc["fine"], sc["depth"], 4, "uniform", 0.1)
         return res["depth_net_rgb_map"], res["depth_net_disp_map"]

@@ -105,22 +105,17 @@ def test_render_only_pipeline_with_reference_checkpoints(tmp_path, gpu_modules):
     assert sd["all_pts"].shape == (2 * H * W * 16, 3) and sd["all_weights"].shape == (2 * H * W * 16,)
 
 
-@pytest.mark.gpu
-def test_render_cli_counterpart(tmp_path, gpu_modules):
-    """`python -m nerf_sampling_amd.experiments.render -d lego -rt [-nf]`: the reference's CLI flow
-    (render.py:135-272) on a synthetic 'lego' with production-size networks and reference-layout paths."""
-    from click.testing import CliRunner
-
-    from nerf_sampling_amd.experiments.render import main
+def _cli_root(tmp_path, m, n_test=2):
+    """A reference-layout root (dataset/lego, pretrained/nerf|depth_net/lego/...) holding a random 'lego' dataset of 32x32
+    files (the yaml has half_res: True) and the modules' weights as 200000.tar checkpoints."""
     from nerf_sampling_amd.synthetic import pose_spherical
 
-    m = gpu_modules("lego_synth")
     root = str(tmp_path)
-    H = W = 16   # files are 32x32, the yaml has half_res: True
+    H = W = 16
     rng = np.random.default_rng(1)
     frames = [np.concatenate([rng.integers(0, 256, (2 * H, 2 * W, 3), dtype=np.uint8), np.full((2 * H, 2 * W, 1), 255, np.uint8)], -1)
-              for _ in range(2)]
-    poses = [pose_spherical(a, -30.0, 4.0).numpy() for a in (0.0, 90.0)]
+              for _ in range(n_test)]
+    poses = [pose_spherical(a, -30.0, 4.0).numpy() for a in (0.0, 90.0)[:n_test]]
     _write_dataset(os.path.join(root, "dataset", "lego"), {"train": frames[:1], "val": frames[:1], "test": frames},
                    {"train": poses[:1], "val": poses[:1], "test": poses})
     os.makedirs(os.path.join(root, "pretrained", "nerf", "lego"))
@@ -133,6 +128,18 @@ def test_render_cli_counterpart(tmp_path, gpu_modules):
     torch.save({"global_step": 200000, "depth_network": m["depth"].state_dict(),
                 "sampling_optimizer_state_dict": torch.optim.Adam(m["depth"].parameters()).state_dict()},
                os.path.join(root, "pretrained", "depth_net", "lego", "files", "sampler_experiment", "200000.tar"))
+    return root
+
+
+@pytest.mark.gpu
+def test_render_cli_counterpart(tmp_path, gpu_modules):
+    """`python -m nerf_sampling_amd.experiments.render -d lego -rt [-nf]`: the reference's CLI flow
+    (render.py:135-272) on a synthetic 'lego' with production-size networks and reference-layout paths."""
+    from click.testing import CliRunner
+
+    from nerf_sampling_amd.experiments.render import main
+
+    root = _cli_root(tmp_path, gpu_modules("lego_synth"))
     try:
         for flags, exp in (([], "lego_depth_net_render_n_samples_2_distance_0.01_sampling_mode_uniform"),
                            (["-nf"], "lego_nerf_full_render")):
@@ -144,3 +151,43 @@ def test_render_cli_counterpart(tmp_path, gpu_modules):
             assert os.path.exists(os.path.join(out_dir, "000.png")) and os.path.exists(os.path.join(out_dir, "psnr.txt"))
     finally:
         torch.set_default_device("cpu")   # the CLI switches the global default device like the reference does
+
+
+@pytest.mark.gpu
+def test_render_cli_experiments_sweep(tmp_path, gpu_modules):
+    """`render -d lego -rt -e`: the reference's automatic sweep (render.py:232-261) run END TO END -- 2 sampling modes x
+    n_samples in {2, 32, 64, 128} x distance in {0.1, 0.3, 0.5, 1} = 32 render-only trainers -- and the
+    experiments_results.txt it writes, line by line in the reference's format."""
+    import re
+
+    from click.testing import CliRunner
+
+    from nerf_sampling_amd.experiments.render import main
+
+    root = _cli_root(tmp_path, gpu_modules("lego_synth"), n_test=1)
+    try:
+        res = CliRunner().invoke(main, ["-d", "lego", "-rt", "-e", "--root", root, "--dtype", "f32"], catch_exceptions=False)
+        assert res.exit_code == 0, res.output
+    finally:
+        torch.set_default_device("cpu")
+    base = os.path.join(root, "logs", "lego", "experiments")
+    lines = open(os.path.join(base, "experiments_results.txt")).read().split("\n")
+    want = ["Experiments"]
+    for mode in ("uniform", "gaussian"):
+        want += ["", f"Sampling mode: {mode}", ""]
+        for n in (2, 32, 64, 128):
+            want.append(f"N_samples: {n}:")
+            want += [f"    Distance: {d}, PSNR: " for d in (0.1, 0.3, 0.5, 1)]
+    assert len(lines) == len(want) + 1 and lines[-1] == ""
+    psnrs = []
+    for got, exp in zip(lines, want):
+        if exp.startswith("    Distance"):
+            assert got.startswith(exp) and re.fullmatch(r"-?\d+\.\d\d", got[len(exp):]), (got, exp)
+            psnrs.append(float(got[len(exp):]))
+        else:
+            assert got == exp, (got, exp)
+    assert len(psnrs) == 32 and all(np.isfinite(psnrs)) and len(set(psnrs)) > 8      # the settings really differ
+    for mode, n, d in (("uniform", 2, 0.1), ("gaussian", 128, 1)):
+        out_dir = os.path.join(base, mode, f"lego_depth_net_render_n_samples_{n}_distance_{d}_sampling_mode_{mode}",
+                               "renderonly_test_200000")
+        assert os.path.exists(os.path.join(out_dir, "000.png")) and os.path.exists(os.path.join(out_dir, "psnr.txt"))

@@ -343,6 +343,46 @@ def main():
             out[f"z_{tag}"] = net.eval()(o_s, d_s)
         save("depthnet_shapes", **out)
 
+        # ---- the reference's pytest=True determinism hook (Trainer.py:621-624, run_nerf_helpers.py:265-273,
+        #      sampling_trainer.py:188-193): numpy draws under np.random.seed(0) replace torch's.  Appended after every
+        #      other fixture, own generator.  Two facts of the reference recorded here (probe, torch 2.10):
+        #      (i) torch.tensor(np.random.rand(..)) is float64, so every output downstream of a draw is float64;
+        #      (ii) for that reason sample_as_in_NeRF(pytest=True) raises "mat1 and mat2 must have the same dtype" at the
+        #      MLP in every configuration (even perturb = 0: sample_pdf's linspace is float64) -- the hook only works
+        #      operator by operator, which is what is captured.  sample_coarse_points is driven with a query function
+        #      that casts the float64 points to float32 before the reference's own run_network.
+        print("pytest=True hook")
+        g3 = torch.Generator().manual_seed(2024)
+        out = {}
+        bins = torch.sort(torch.rand(24, 63, generator=g3) * 4 + 2, -1).values
+        w = torch.rand(24, 62, generator=g3) ** 3
+        w[0] = 0.0
+        out["pdf_bins"], out["pdf_weights"] = bins, w
+        out["pdf_det"] = ref.helpers.sample_pdf(bins, w, 128, det=True, pytest=True)
+        out["pdf_rnd"] = ref.helpers.sample_pdf(bins, w, 128, det=False, pytest=True)
+        tr = make_trainer(ref)
+        raw = torch.randn(40, 64, 4, generator=g3)
+        raw[..., 3] = raw[..., 3] * 30.0 + 5.0
+        z = torch.sort(torch.rand(40, 64, generator=g3) * 4 + 2, -1).values
+        rd = torch.randn(40, 3, generator=g3)
+        res = tr.raw2outputs(raw, z, rd, 0.7, True, pytest=True)
+        out["r2o_raw"], out["r2o_z"], out["r2o_rays_d"], out["r2o_std"] = raw, z, rd, 0.7
+        for nm, v in zip(("rgb", "disp", "acc", "depth", "density", "alphas", "weights"), res):
+            out[f"r2o_{nm}"] = v
+        n = "tiny_synth"
+        rb = batch64[sel][:80]
+        kw, _, _ = render_kwargs(ref, tr, nets[n]["coarse"], nets[n]["fine"], nets[n]["depth"])
+        query32 = lambda pts, vd, fn: kw["network_query_fn"](pts.float(), vd, fn)  # noqa: E731
+        for lindisp in (True, False):
+            res = tr.sample_coarse_points(
+                near=rb[:, 6:7], far=rb[:, 7:8], perturb=1.0, N_rays=rb.shape[0], N_samples=64, viewdirs=rb[:, -3:],
+                network_fn=nets[n]["coarse"], network_query_fn=query32, rays_o=rb[:, 0:3], rays_d=rb[:, 3:6],
+                raw_noise_std=0.0, white_bkgd=True, pytest=True, lindisp=lindisp)
+            out[f"coarse_lin{int(lindisp)}_rgb_map"], out[f"coarse_lin{int(lindisp)}_weights"] = res[0], res[3]
+            out[f"coarse_lin{int(lindisp)}_z"] = res[5]
+        out["coarse_ray_batch"] = rb
+        save("pytest_hook", **out)
+
     if "--stats" in sys.argv:
         w = out  # noqa
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
