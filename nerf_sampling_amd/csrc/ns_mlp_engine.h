@@ -180,13 +180,20 @@ __host__ __device__ constexpr int seg_slabs(int cpb, int nbo, int nblk) {
 #define NS_GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 
 // LDS-DMA of 16 (or 4) bytes per lane: LDS address = wave-uniform base (M0) + lane * size, global address per lane.
+// M0 is compiler-reserved: it cannot be declared as a clobber (hipcc only warns and does not honour it), so every
+// statement that writes it saves the old value into a scratch SGPR first and restores it before it ends
+// (cdna_hip_programming.md section 5.7): the code generator may keep whatever it likes in M0 around these statements.
 __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
   const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gptr) : "memory");   // (M0 is compiler-reserved; nothing else in these kernels uses it)
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(m0v), "v"(gptr) : "memory");
 }
 __device__ __forceinline__ void lds_dma4(const void* gptr, uint32_t lds_base) {
   const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(gptr) : "memory");   // (M0 is compiler-reserved; nothing else in these kernels uses it)
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(m0v), "v"(gptr) : "memory");
 }
 
 // Ring of kRingDepth LDS slots + a kFragDepth-deep register pipeline of A fragments.
@@ -253,18 +260,22 @@ struct Pipe {
         const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
         const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
         static_assert(LPW == 1 || LPW == 2 || LPW == 4, "pieces per wave");
+        uint32_t keep;      // M0 saved and restored inside the statement (see lds_dma16)
         if constexpr (LPW == 4)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                       "global_load_lds_dwordx4 %1, %2\n\t"
-                       "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                       "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                       "global_load_lds_dwordx4 %1, %2 offset:3072" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %2, %3\n\t"
+                       "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                       "global_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+                       "global_load_lds_dwordx4 %2, %3 offset:3072\n\t"
+                       "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
         else if constexpr (LPW == 2)
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                       "global_load_lds_dwordx4 %1, %2\n\t"
-                       "global_load_lds_dwordx4 %1, %2 offset:1024" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                       "global_load_lds_dwordx4 %2, %3\n\t"
+                       "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+                       "s_mov_b32 m0, %0" : "=&s"(keep) : "s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
         else
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "s"(m0v), "v"(lane_off), "s"(sbase) : "memory");
       }
       issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
       issue_slot = next_slot(issue_slot);
@@ -318,8 +329,9 @@ struct Pipe {
     const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
     const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
     const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(m0v), "v"(lane_off), "s"(sbase),
-                 "n"(I * kChunkBytes) : "memory");
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(m0v), "v"(lane_off), "s"(sbase), "n"(I * kChunkBytes) : "memory");
   }
   __device__ __forceinline__ void issue_advance() {
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
