@@ -268,6 +268,13 @@ int ns_points_backward(const float* dpts_dev, const float* d_dev, int64_t R, int
 /* torch.optim.Adam update (no weight decay / amsgrad), step counted from 1 */
 int ns_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
                  float beta1, float beta2, float eps, int step, void* stream);
+/* the same update with the step count read from *step_dev (>= 1) and, when lr_dev is not NULL, the learning rate from
+ * *lr_dev: nothing in the launch changes from step to step, so a captured hipGraph of the whole training step
+ * (forward, backward, update) can be replayed; ns_add_i32 advances the counter on the stream                       */
+int ns_adam_step_dev(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
+                     const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev,
+                     void* stream);
+int ns_add_i32(int* x_dev, int delta, void* stream);
 
 /* ---- timing helpers (hipEvent_t as void*) used by bench.py for the live roofline figure --------- */
 int ns_event_create(void** ev);

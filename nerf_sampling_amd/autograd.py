@@ -251,7 +251,58 @@ def depthnet_forward_train(net, o: Tensor, d: Tensor) -> Tensor:
 # ---- Adam on the HIP kernel, state-dict compatible with torch.optim.Adam -------------------------------------
 class HipAdam(torch.optim.Adam):
     """torch.optim.Adam whose step() runs ns_adam_step; state ('step', 'exp_avg', 'exp_avg_sq') and therefore
-    state_dict()/load_state_dict() are torch's, so the reference's checkpoints round-trip (utils.py:59-122)."""
+    state_dict()/load_state_dict() are torch's, so the reference's checkpoints round-trip (utils.py:59-122).
+
+    ``use_device_step()`` moves the step counter (and the learning rate) into device memory: step() then launches
+    ns_add_i32 + ns_adam_step_dev and reads nothing from the host, which is what lets trainers.GraphedDepthNetStep
+    capture forward + backward + update in one hipGraph.  The per-parameter 'step' entries of the state are brought up
+    to date whenever the state is read (state_dict())."""
+
+    _dev_step: Optional[Tensor] = None
+    _dev_lr: Optional[Tensor] = None
+    _host_steps = 0          # steps taken through the device counter (eager calls and graph replays alike)
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p)
+            st["exp_avg_sq"] = torch.zeros_like(p)
+        return st
+
+    def use_device_step(self):
+        """Switch to the device-resident step counter (idempotent).  All parameters must share one step count."""
+        if self._dev_step is not None:
+            return
+        params = [p for g in self.param_groups for p in g["params"]]
+        steps = {int(self.state[p]["step"].item()) if len(self.state[p]) else 0 for p in params}
+        if len(steps) > 1 or len(self.param_groups) != 1:
+            raise NotImplementedError("the device step counter needs one parameter group and one common step count")
+        dev = params[0].device
+        self._host_steps = steps.pop() if steps else 0
+        self._dev_step = torch.full((1,), self._host_steps, dtype=torch.int32, device=dev)
+        self._dev_lr = torch.full((1,), float(self.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
+        self._lr_seen = float(self.param_groups[0]["lr"])
+        for p in params:
+            self._init_state(p)
+
+    def note_replayed_step(self):
+        """A captured graph containing step() was replayed once."""
+        self._host_steps += 1
+
+    def sync_device_lr(self):
+        """Publish param_groups[0]['lr'] to the device scalar the captured update reads (one tiny fill, only on change)."""
+        lr = float(self.param_groups[0]["lr"])
+        if self._dev_lr is not None and lr != self._lr_seen:
+            self._dev_lr.fill_(lr)
+            self._lr_seen = lr
+
+    def state_dict(self):
+        if self._dev_step is not None:
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"].fill_(float(self._host_steps))
+        return super().state_dict()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -260,16 +311,24 @@ class HipAdam(torch.optim.Adam):
             b1, b2 = group["betas"]
             if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("HipAdam implements plain Adam only")
+            if self._dev_step is not None:
+                capturing = torch.cuda.is_current_stream_capturing()
+                if not capturing:
+                    self.sync_device_lr()
+                    self._host_steps += 1
+                check(lib.ns_add_i32(_ptr(self._dev_step), 1, _stream(self._dev_step.device)), "ns_add_i32")
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p)
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
+                st = self._init_state(p)
                 g = p.grad.contiguous()
+                if self._dev_step is not None:
+                    check(lib.ns_adam_step_dev(_ptr(p.data), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), p.numel(),
+                                               float(group["lr"]), _ptr(self._dev_lr), float(b1), float(b2),
+                                               float(group["eps"]), _ptr(self._dev_step), _stream(p.device)),
+                          "ns_adam_step_dev")
+                    continue
+                st["step"] += 1
                 check(lib.ns_adam_step(_ptr(p.data), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]), p.numel(),
                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                        int(st["step"].item()), _stream(p.device)), "ns_adam_step")

@@ -149,6 +149,26 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   }
 }
 
+// the same update with the step counter (and optionally the learning rate) read from device memory: a captured hipGraph
+// of the training step replays it unchanged while the bias corrections follow the counter
+__global__ void __launch_bounds__(256)
+adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                int64_t n, float lr, const float* __restrict__ lr_dev, float b1, float b2, float eps,
+                const int* __restrict__ step_dev) {
+  const float step = static_cast<float>(*step_dev);
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  if (lr_dev) lr = *lr_dev;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = m[i] = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = v[i] = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ void add_i32_kernel(int* __restrict__ x, int delta) { *x += delta; }
+
 }  // namespace
 
 extern "C" {
@@ -228,6 +248,24 @@ int ns_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, i
   const float bc2 = 1.f - powf(beta2, static_cast<float>(step));
   adam_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2,
                                                                      eps, bc1, bc2);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_adam_step_dev(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, int64_t n, float lr,
+                     const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev, void* stream) {
+  NS_REQUIRE(n >= 0, "bad argument");
+  if (n == 0) return NS_OK;
+  NS_REQUIRE(p_dev && g_dev && m_dev && v_dev && step_dev, "null pointer");
+  adam_dev_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(p_dev, g_dev, m_dev, v_dev, n, lr, lr_dev, beta1,
+                                                                         beta2, eps, step_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_add_i32(int* x_dev, int delta, void* stream) {
+  NS_REQUIRE(x_dev, "null pointer");
+  add_i32_kernel<<<1, 1, 0, ns::as_stream(stream)>>>(x_dev, delta);
   NS_LAUNCH_CHECK();
   return NS_OK;
 }

@@ -320,10 +320,13 @@ def render_rays(ray_batch, network_fn, network_query_fn, N_samples, trainer, ret
     (rgb_map, disp_map, _acc, _depth, _density, _alphas, _weights) = trainer.raw2outputs(
         raw=depth_net_raw, z_vals=depth_net_z_vals, rays_d=rays_d, raw_noise=raw_noise_std, white_bkdg=white_bkgd,
         pytest=pytest)  # (sic) misspelled keywords, as in the reference: noise 0, white background
+    # host copies of the reference (:723-727); `_skip_host_copies` (internal: the graph-captured training step, where a
+    # blocking copy cannot be recorded and nothing reads these three) leaves them on the device
+    to_host = (lambda t: t) if kwargs.get("_skip_host_copies", False) else (lambda t: t.cpu())
     ret = {"depth_net_rgb_map": rgb_map, "depth_net_disp_map": disp_map, "depth_net_z_vals": depth_net_z_vals,
-           "max_z_vals": max_z_vals, "depth_net_pts": depth_net_pts.detach().cpu(), "max_pts": max_pts.cpu()}
+           "max_z_vals": max_z_vals, "depth_net_pts": to_host(depth_net_pts.detach()), "max_pts": to_host(max_pts)}
     if retraw:
-        ret["raw"] = depth_net_raw.detach().cpu()
+        ret["raw"] = to_host(depth_net_raw.detach())
     return ret
 
 

@@ -11,7 +11,18 @@ import torch.nn as nn
 from . import ops
 
 img2mse = lambda x, y: torch.mean((x - y) ** 2)  # noqa: E731   run_nerf_helpers.py:9
-mse2psnr = lambda x: -10.0 * torch.log(x) / torch.log(torch.tensor([10.0], device=x.device))  # noqa: E731
+_TEN = {}
+
+
+def mse2psnr(x):
+    """-10 log(x) / log(10) as run_nerf_helpers.py:10; the constant tensor is cached per device (creating it per call is
+    a blocking host-to-device copy, i.e. a stream synchronisation inside every training step)."""
+    ten = _TEN.get(x.device)
+    if ten is None:
+        ten = _TEN[x.device] = torch.tensor([10.0], device=x.device)
+    return -10.0 * torch.log(x) / torch.log(ten)
+
+
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)  # noqa: E731
 
 

@@ -32,7 +32,8 @@ class Trainer:
                  precrop_frac=0.5, i_weights=10000, i_testset=100, i_video=5000, i_print=100,
                  input_dims_embed: int = 1, save_train_set_render: bool = True, depth_net_lr: float = 0.0001,
                  train_depth_net_only: bool = False, trial=None, single_image=False, single_ray=False,
-                 save_scene_data=False, compare_nerf=False, use_nerf_max_pts=False, use_full_nerf=False):
+                 save_scene_data=False, compare_nerf=False, use_nerf_max_pts=False, use_full_nerf=False,
+                 hip_graph: bool = True):
         for k, v in list(locals().items()):
             if k != "self":
                 setattr(self, k, v)
@@ -162,11 +163,14 @@ class Trainer:
                                render_kwargs_test)
         images, poses, rays_rgb, i_batch = self.prepare_raybatch_tensor_if_batching_random_rays(poses, images, i_train)
         psnr = None
+        # hip_graph (not in the reference; default on): the step is captured as one hipGraph after two eager steps
+        step = (self.graphed_optimization_loop(sampling_optimizer, render_kwargs_train)
+                if self.hip_graph and dev == "cuda" and hasattr(sampling_optimizer, "use_device_step")
+                else lambda rays, it, tgt: self.core_optimization_loop(sampling_optimizer, render_kwargs_train, rays, it, tgt))
         for i in range(self.start + 1, N_iters):
             rays_rgb, i_batch, batch_rays, target_s = self.sample_random_ray_batch(rays_rgb, i_batch, i_train, images,
                                                                                    poses, i)
-            loss, depth_net_loss, psnr, _ = self.core_optimization_loop(sampling_optimizer, render_kwargs_train,
-                                                                         batch_rays, i, target_s)
+            loss, depth_net_loss, psnr, _ = step(batch_rays, i, target_s)
             self.update_learning_rate(optimizer)
             if i % self.i_print == 0:
                 print(f"[TRAIN] Iter: {i} Loss: {float(loss)} depth_net_loss: {float(depth_net_loss)} "
@@ -245,21 +249,89 @@ class Trainer:
         target_s = target[sel[:, 0], sel[:, 1]].to(rays_o.device)
         return rays_rgb, i_batch, batch_rays, target_s
 
-    def core_optimization_loop(self, sampling_optimizer, render_kwargs_train, batch_rays, i, target_s):
-        """One DepthNet update: (loss, depth_net_loss, psnr, psnr0) -- Trainer.py:506-544.  The two backward
-        calls of the reference accumulate into the same .grad; one backward of the sum is identical."""
-        from .run_nerf_helpers import img2mse, mse2psnr
+    def _optimization_step(self, sampling_optimizer, render_kwargs_train, batch_rays, i, target_s, **render_extra):
+        """forward + two losses + backward + update; (img_loss, depth_net_loss) as device scalars."""
+        from .run_nerf_helpers import img2mse
 
         rgb, _disp, extras = nerf_utils.render(self.H, self.W, self.K, chunk=self.chunk, rays=batch_rays,
-                                               verbose=i < 10, retraw=True, **render_kwargs_train)
+                                               verbose=i < 10, retraw=True, **render_kwargs_train, **render_extra)
         sampling_optimizer.zero_grad()
         img_loss = img2mse(rgb, target_s)
-        psnr = mse2psnr(img_loss.detach())
         depth_net_loss = torch.nn.functional.mse_loss(extras["depth_net_z_vals"], extras["max_z_vals"])
         (depth_net_loss + img_loss).backward()
         sampling_optimizer.step()
+        return img_loss.detach(), depth_net_loss.detach()
+
+    def core_optimization_loop(self, sampling_optimizer, render_kwargs_train, batch_rays, i, target_s):
+        """One DepthNet update: (loss, depth_net_loss, psnr, psnr0) -- Trainer.py:506-544.  The two backward
+        calls of the reference accumulate into the same .grad; one backward of the sum is identical."""
+        from .run_nerf_helpers import mse2psnr
+
+        img_loss, depth_net_loss = self._optimization_step(sampling_optimizer, render_kwargs_train, batch_rays, i, target_s)
+        psnr = mse2psnr(img_loss)
         render_kwargs_train["depth_network"].repack()
-        return img_loss.detach(), depth_net_loss.detach(), psnr, None
+        return img_loss, depth_net_loss, psnr, None
+
+    def graphed_optimization_loop(self, sampling_optimizer, render_kwargs_train):
+        """core_optimization_loop as ONE hipGraph replay per step (see GraphedDepthNetStep): same arguments after the
+        first two, same return value, same updates bit for bit."""
+        return GraphedDepthNetStep(self, sampling_optimizer, render_kwargs_train)
+
+
+class GraphedDepthNetStep:
+    """Trainer.core_optimization_loop (Trainer.py:506-544) captured as one hipGraph.
+
+    A training step at the reference's batch size (N_rand = 1024 rays) is ~450 small kernels: the frozen field's
+    64 + 128 vanilla pass, the DepthNet forward / backward layer by layer, the NeRF input gradient, 82 Adam updates.
+    Eagerly the step is bound by the host side of those launches; captured once (torch.cuda.CUDAGraph = hipGraph on
+    ROCm) and replayed, the host issues ONE launch per step.  What makes the step capturable: HipAdam's device-resident
+    step counter / learning rate (ns_adam_step_dev), render_rays without its three host copies (nothing in the step
+    reads them), and fixed batch shapes.  The first ``warmup`` calls run eagerly (they are real steps and warm every
+    lazily-built cache); the next call captures and replays.  A batch of another shape runs eagerly.
+
+    Call: ``step(batch_rays, i, target_s) -> (img_loss, depth_net_loss, psnr, None)`` like core_optimization_loop."""
+
+    def __init__(self, trainer, sampling_optimizer, render_kwargs_train, warmup: int = 2):
+        self.tr, self.opt, self.kw, self.warmup = trainer, sampling_optimizer, render_kwargs_train, warmup
+        self.calls, self.graph, self.shape = 0, None, None
+        self.opt.use_device_step()
+        # everything the captured kernels point into must outlive the graph: packed weight streams of the frozen networks
+        self._keep = [n.packed() for n in (render_kwargs_train.get("network_fn"), render_kwargs_train.get("network_fine"))
+                      if n is not None]
+
+    def _eager(self, batch_rays, i, target_s):
+        from .run_nerf_helpers import mse2psnr
+
+        img_loss, dn_loss = self.tr._optimization_step(self.opt, self.kw, batch_rays, i, target_s, _skip_host_copies=True)
+        self.kw["depth_network"].repack()
+        return img_loss, dn_loss, mse2psnr(img_loss), None
+
+    def _capture(self, batch_rays, target_s):
+        self.shape = (tuple(batch_rays.shape), tuple(target_s.shape))
+        self.rays, self.target = batch_rays.clone(), target_s.clone()
+        self.opt.zero_grad(set_to_none=True)           # backward inside the capture allocates the grads in the graph's pool
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.img_loss, self.dn_loss = self.tr._optimization_step(self.opt, self.kw, self.rays, 1 << 30, self.target,
+                                                                     _skip_host_copies=True)
+
+    def __call__(self, batch_rays, i, target_s):
+        from .run_nerf_helpers import mse2psnr
+
+        self.calls += 1
+        if self.calls <= self.warmup or (self.shape is not None and
+                                         self.shape != (tuple(batch_rays.shape), tuple(target_s.shape))):
+            return self._eager(batch_rays, i, target_s)
+        if self.graph is None:
+            self._capture(batch_rays, target_s)        # records, does not execute
+        self.rays.copy_(batch_rays)
+        self.target.copy_(target_s)
+        self.opt.sync_device_lr()
+        self.graph.replay()
+        self.opt.note_replayed_step()
+        self.kw["depth_network"].repack()
+        return self.img_loss, self.dn_loss, mse2psnr(self.img_loss), None
 
 
 class BlenderTrainer(Trainer):

@@ -105,6 +105,16 @@ def test_hip_adam_matches_torch_adam():
     assert torch.allclose(a.detach().cpu(), b.detach(), rtol=1e-5, atol=1e-6)
     sd = oa.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}      # torch's layout: checkpoints round-trip
+    # the device-resident step counter / learning rate (what a captured hipGraph of the step replays): same updates
+    oa.use_device_step()
+    for k in range(4):
+        if k == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3e-4
+        grad = torch.randn(300, 17, generator=g)
+        a.grad, b.grad = grad.cuda(), grad.clone()
+        oa.step(); ob.step()
+    assert torch.allclose(a.detach().cpu(), b.detach(), rtol=1e-5, atol=1e-6)
+    assert float(oa.state_dict()["state"][0]["step"]) == float(ob.state_dict()["state"][0]["step"]) == 9.0
 
 
 def test_core_optimization_loop_reduces_loss(gpu_modules):
@@ -284,3 +294,50 @@ def test_use_batching_and_ray_dump(tmp_path, gpu_modules):
     back = load_file(path)
     assert set(back) == {"origins", "pts", "alpha"}
     assert torch.equal(back["origins"], o.cpu()) and torch.equal(back["pts"], pts[:, ::2].cpu()) and torch.equal(back["alpha"], alpha.cpu())
+
+
+def test_graphed_step_equals_eager_step(gpu_modules):
+    """trainers.GraphedDepthNetStep (forward + backward + Adam as ONE hipGraph replay per step) against
+    core_optimization_loop on the same batches: identical losses and bit-identical DepthNet weights and Adam state after
+    six steps (two eager warm-up steps, capture, four replays), and a step counter that checkpoints like torch's."""
+    from nerf_sampling_amd import ops
+    from nerf_sampling_amd.autograd import HipAdam
+
+    ops.set_compute_dtype("f32")
+    base = dict(gpu_modules("tiny_synth"))
+    H = W = 24
+    _, K = O.blender_intrinsics(H, W)
+    o, d, _ = ops.get_rays(H, W, K, O.pose_spherical(20.0, -30.0, 4.0)[:3, :4])
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randint(0, H * W, (128,), generator=g).cuda(), torch.rand(128, 3, generator=g).cuda()) for _ in range(6)]
+    results = {}
+    for mode in ("eager", "graph"):
+        m = dict(base)
+        m["depth"] = copy.deepcopy(base["depth"])
+        for p in m["depth"].parameters():
+            p.requires_grad_(True)
+        tr, kw = _kwargs(m)
+        tr.H, tr.W, tr.K = H, W, K
+        kw.update(near=2.0, far=6.0, ndc=False)
+        opt = HipAdam(list(m["depth"].parameters()), lr=1e-3)
+        opt.use_device_step()          # both runs on ns_adam_step_dev (bias corrections evaluated on the device)
+        step = (tr.graphed_optimization_loop(opt, kw) if mode == "graph"
+                else (lambda rays, i, tgt: tr.core_optimization_loop(opt, kw, rays, i, tgt)))
+        losses = []
+        for i, (idx, tgt) in enumerate(batches):
+            if i == 4:
+                opt.param_groups[0]["lr"] = 5e-4           # a learning-rate change reaches the captured update
+            loss, dn_loss, psnr, _ = step(torch.stack([o[idx], d[idx]], 0), i, tgt)
+            losses.append((float(loss), float(dn_loss), float(psnr)))
+        if mode == "graph":
+            assert step.graph is not None and step.calls == 6
+        sd = opt.state_dict()
+        results[mode] = (losses, [p.detach().clone() for p in m["depth"].parameters()], sd)
+    le, pe, sde = results["eager"]
+    lg, pg, sdg = results["graph"]
+    assert le == lg, (le, lg)
+    assert all(torch.equal(a, b) for a, b in zip(pe, pg))
+    for k in sde["state"]:
+        assert float(sde["state"][k]["step"]) == float(sdg["state"][k]["step"]) == 6.0
+        assert torch.equal(sde["state"][k]["exp_avg_sq"], sdg["state"][k]["exp_avg_sq"])
+    assert le[-1][1] < le[0][1]                            # and it trains

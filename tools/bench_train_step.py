@@ -10,6 +10,7 @@ from nerf_sampling_amd.run_nerf_helpers import NeRF, get_embedder
 from nerf_sampling_amd.trainers import DepthNetTrainer
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+graph = "--graph" in sys.argv
 ops.set_compute_dtype(dtype)
 cfg, params = synthetic.SCENES["lego_synth"], synthetic.make_scene("lego_synth")
 nets = {}
@@ -33,12 +34,15 @@ tr.H, tr.W, tr.K = H, W, K
 o, d, _ = ops.get_rays(H, W, K, synthetic.pose_spherical(30.0, -30.0, 4.0)[:3, :4])
 opt = HipAdam(list(dn.parameters()), lr=1e-4)
 g = torch.Generator().manual_seed(0)
+run = tr.graphed_optimization_loop(opt, kw) if graph else (lambda rays, i, tgt: tr.core_optimization_loop(opt, kw, rays, i, tgt))
+idxs = [torch.randint(0, H * W, (1024,), generator=g).cuda() for _ in range(8)]
+tgts = [torch.rand(1024, 3, generator=g).cuda() for _ in range(8)]
 def step(i):
-    idx = torch.randint(0, H * W, (1024,), generator=g).cuda()
-    return tr.core_optimization_loop(opt, kw, torch.stack([o[idx], d[idx]], 0), i, torch.rand(1024, 3, generator=g).cuda())
+    idx = idxs[i % 8]
+    return run(torch.stack([o[idx], d[idx]], 0), i, tgts[i % 8])
 for i in range(5): step(i)
 torch.cuda.synchronize(); t0 = time.perf_counter(); K_ = 30
 for i in range(K_): loss = step(i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K_
 print(json.dumps({"metric": "DepthNet training step (1024 rays: frozen 64+128 NeRF pass + DepthNet fwd/bwd + Adam)",
-                  "ms_per_iter": 1e3 * dt, "iters_per_s": 1 / dt, "rays_per_s": 1024 / dt, "dtype_frozen_nerf": dtype}))
+                  "hip_graph": graph, "ms_per_iter": 1e3 * dt, "iters_per_s": 1 / dt, "rays_per_s": 1024 / dt, "dtype_frozen_nerf": dtype}))
