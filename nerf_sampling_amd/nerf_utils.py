@@ -119,25 +119,35 @@ def batchify_rays_test(rays_flat, chunk=1024 * 32, **kwargs):
 
 
 def prepare_rays(c2w, c2w_staticcam, use_viewdirs, ndc, H, W, K, near, far, rays):
-    """rays [R,11], rays_o, rays_d, shape -- nerf_utils.py:156-188 (ndc=False only)."""
+    """rays [R,11], rays_o, rays_d, shape -- nerf_utils.py:156-188 (ndc=False only).  ``c2w_staticcam`` (:172-176, "visualize
+    effect of viewdirs"): the view directions come from ``c2w`` (or ``rays``), origins and directions from the static
+    camera."""
     if ndc:
         raise NotImplementedError("NDC rays (LLFF forward-facing scenes) are out of scope (SURVEY.md section 2)")
-    if c2w_staticcam is not None:
-        raise NotImplementedError("c2w_staticcam is not supported")
-    if c2w is not None:
+    if c2w is not None and c2w_staticcam is None:
         rays_o, rays_d, viewdirs, batch = ops.get_rays(H, W, K, c2w, near=near, far=far, want_batch=True)
         sh = (H, W, 3)
         if not use_viewdirs:
             batch = batch[:, :8].contiguous()
         return batch, rays_o, rays_d, sh
-    rays_o, rays_d = rays
-    sh = rays_d.shape
+    viewdirs = None
+    if c2w is not None:
+        rays_o, rays_d, viewdirs = ops.get_rays(H, W, K, c2w)          # viewdirs = rays_d / |rays_d|, [H*W, 3]
+        sh = (H, W, 3)
+    else:
+        rays_o, rays_d = rays
+        sh = rays_d.shape
+        if use_viewdirs:
+            viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+            viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    if use_viewdirs and c2w_staticcam is not None:
+        rays_o, rays_d, _ = ops.get_rays(H, W, K, c2w_staticcam)
+        sh = (H, W, 3)
     rays_o = torch.reshape(rays_o, [-1, 3]).float()
     rays_d = torch.reshape(rays_d, [-1, 3]).float()
     near_t, far_t = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
     batch = torch.cat([rays_o, rays_d, near_t, far_t], -1)
     if use_viewdirs:
-        viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
         batch = torch.cat([batch, viewdirs], -1)
     return batch, rays_o, rays_d, sh
 

@@ -52,13 +52,17 @@ def camera_rays(H: int, W: int, K, c2w: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def ray_batch_from_camera(
-    H: int, W: int, K, c2w: Tensor, near: float, far: float, use_viewdirs: bool = True
+    H: int, W: int, K, c2w: Tensor, near: float, far: float, use_viewdirs: bool = True,
+    c2w_staticcam: Optional[Tensor] = None,
 ):
-    """[R, 11] = [o, d, near, far, unit viewdir] as nerf_utils.py:156-188 (ndc=False)."""
+    """[R, 11] = [o, d, near, far, unit viewdir] as nerf_utils.py:156-188 (ndc=False).  With ``c2w_staticcam`` the view
+    directions are those of ``c2w`` and the rays those of the static camera (:172-176)."""
     rays_o, rays_d = camera_rays(H, W, K, c2w)
     shape = rays_d.shape
     view = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     view = view.reshape(-1, 3).float()
+    if use_viewdirs and c2w_staticcam is not None:
+        rays_o, rays_d = camera_rays(H, W, K, c2w_staticcam)
     o = rays_o.reshape(-1, 3).float()
     d = rays_d.reshape(-1, 3).float()
     nr = near * torch.ones_like(d[..., :1])

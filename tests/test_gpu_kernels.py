@@ -49,6 +49,24 @@ def test_get_rays(ops, golden, tag):
     assert torch.equal(d2, d[r0 * W : r1 * W]) and torch.equal(v2, v[r0 * W : r1 * W])
 
 
+def test_prepare_rays_staticcam(ops, golden):
+    """prepare_rays(c2w, c2w_staticcam) against the reference (nerf_utils.py:172-176): columns 8..10 are the view directions
+    of c2w, columns 0..5 the rays of the static camera; origins bit-exact, directions to 2e-6 as test_get_rays."""
+    from nerf_sampling_amd import nerf_utils
+
+    g = golden("staticcam")
+    H, W = int(g["H"]), int(g["W"])
+    batch, o, d, sh = nerf_utils.prepare_rays(c2w=T(g["c2w"]), c2w_staticcam=T(g["c2w_staticcam"]), use_viewdirs=True,
+                                              ndc=False, H=H, W=W, K=g["K"], near=2.0, far=6.0, rays=None)
+    assert tuple(sh) == (H, W, 3) and batch.shape == (H * W, 11)
+    close(batch[:, 0:3], g["ray_batch"][:, 0:3], 0, 0)
+    close(batch[:, 3:6], g["ray_batch"][:, 3:6], 0, 2e-6)
+    close(batch[:, 6:8], g["ray_batch"][:, 6:8], 0, 0)
+    close(batch[:, 8:11], g["ray_batch"][:, 8:11], 0, 2e-6)
+    assert not np.allclose(g["ray_batch"][:, 8:11], g["ray_batch"][:, 3:6] / np.linalg.norm(g["ray_batch"][:, 3:6], axis=-1, keepdims=True), atol=1e-3)
+    close(o, g["rays_o"].reshape(-1, 3), 0, 0)
+
+
 def test_get_rays_empty(ops, golden):
     g = golden("rays_5x7")
     o, d, v = ops.get_rays(5, 7, g["K"], g["c2w"], row0=2, row1=2)

@@ -331,3 +331,13 @@ def test_pytest_hook_coarse_jitter(golden, scenes, lindisp):
     res = O.raw2outputs(O.run_network(sc["coarse"], pts, rb[:, -3:]), z, rb[:, 3:6], 0.0, True)
     close(res[0], g[f"coarse_lin{int(lindisp)}_rgb_map"], 2e-4, 2e-5)
     close(res[6], g[f"coarse_lin{int(lindisp)}_weights"], 2e-4, 2e-5)
+
+
+def test_rays_staticcam(golden):
+    """prepare_rays with c2w_staticcam (nerf_utils.py:172-176): view directions of c2w, rays of the static camera."""
+    g = golden("staticcam")
+    batch, o, d, _ = O.ray_batch_from_camera(int(g["H"]), int(g["W"]), g["K"], T(g["c2w"]), 2.0, 6.0,
+                                             c2w_staticcam=T(g["c2w_staticcam"]))
+    close(batch, g["ray_batch"], 0, 0)
+    close(o.reshape(g["rays_o"].shape), g["rays_o"], 0, 0)
+    close(d.reshape(g["rays_d"].shape), g["rays_d"], 0, 0)

@@ -174,7 +174,7 @@ def test_render_cli_experiments_sweep(tmp_path, gpu_modules):
     lines = open(os.path.join(base, "experiments_results.txt")).read().split("\n")
     want = ["Experiments"]
     for mode in ("uniform", "gaussian"):
-        want += ["", f"Sampling mode: {mode}", ""]
+        want += ([""] if mode == "uniform" else ["", ""]) + [f"Sampling mode: {mode}", ""]    # "\n\nSampling mode: ..\n\n"
         for n in (2, 32, 64, 128):
             want.append(f"N_samples: {n}:")
             want += [f"    Distance: {d}, PSNR: " for d in (0.1, 0.3, 0.5, 1)]

@@ -9,7 +9,7 @@ from nerf_sampling_amd.run_nerf_helpers import get_embedder
 from nerf_sampling_amd.trainers import DepthNetTrainer
 
 dev = torch.device("cuda", 0)
-fine, dn, params = bench.build_modules("lego_synth", dev)
+_coarse, fine, dn, params = bench.build_modules("shapes_fit", dev)
 H = W = 800
 _, K = synthetic.blender_intrinsics(H, W)
 poses = synthetic.render_poses(40)[:, :3, :4]
@@ -32,3 +32,11 @@ with torch.no_grad():
             rgb, disp, ex = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], _blocking_host_copies=blocking, **kw)
             torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
         print(f"{label:48s}", " ".join(f"{t:6.1f}" for t in ts))
+    # the loop experiments/render.py runs: render_path keeps frame i's host copies in flight under frame i+1's kernels
+    kw["network_query_fn"] = nerf_utils.standard_query_fn(lambda i, v, f: q(i, v, f))
+    n = int(os.environ.get("NS_API_FRAMES", "8"))
+    nerf_utils.render_path(poses[:3], [H, W, float(K[0][0])], K, tr.chunk, kw, step=0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nerf_utils.render_path(poses[3 : 3 + n], [H, W, float(K[0][0])], K, tr.chunk, kw, step=0)
+    torch.cuda.synchronize()
+    print(f"render_path, {n} frames: {1e3 * (time.perf_counter() - t0) / n:.1f} ms/frame")

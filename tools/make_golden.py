@@ -383,6 +383,14 @@ def main():
         out["coarse_ray_batch"] = rb
         save("pytest_hook", **out)
 
+        # ---- prepare_rays with c2w_staticcam (nerf_utils.py:172-176): view directions of one camera, rays of another
+        print("a1 c2w_staticcam")
+        K57, c2w_a = camera(5, 7, -117.0)
+        _, c2w_b = camera(5, 7, 64.0)
+        batch, o, d, sh = ref.nerf_utils.prepare_rays(c2w=c2w_a, c2w_staticcam=c2w_b, use_viewdirs=True, ndc=False, H=5, W=7,
+                                                      K=K57, near=2.0, far=6.0, rays=None)
+        save("staticcam", H=5, W=7, K=K57, c2w=c2w_a, c2w_staticcam=c2w_b, ray_batch=batch, rays_o=o, rays_d=d)
+
     if "--stats" in sys.argv:
         w = out  # noqa
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
