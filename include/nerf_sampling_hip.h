@@ -82,6 +82,16 @@ typedef struct ns_weights ns_weights; /* opaque */
  * feature_linear (no activation) is composed with views_linears.0 at pack time, in fp64.   */
 int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* const* b, int dtype,
                  ns_weights** out);
+/* The full signature of the reference's NeRF (run_nerf_helpers.py:67-134): any `skips` list (bit i of skip_mask set
+ * <=> i in skips; every skip must precede the last layer, D <= 32) and both head variants.  use_viewdirs != 0: as
+ * ns_pack_nerf (w/b: D + 4 tensors; raw has 4 channels whatever output_ch says, :126-131).  use_viewdirs == 0: the
+ * head is output_linear (W -> output_ch, :132-133; w/b: D + 1 tensors, pts_linears.0..D-1 then output_linear), the
+ * network takes no view directions, and raw has output_ch channels (create_nerf builds 5 with N_importance > 0,
+ * nerf_utils.py:405-406).                                                                                        */
+int ns_pack_nerf_ex(int D, int W, uint32_t skip_mask, int use_viewdirs, int output_ch,
+                    const float* const* w, const float* const* b, int dtype, ns_weights** out);
+/* channels of the raw output of a packed NeRF (4, or output_ch without view directions) */
+int ns_nerf_out_channels(const ns_weights* net);
 /* DepthNet(hidden_sizes, cat_hidden_sizes, multires=10) (depth_net.py:10-169).  w/b: 3*n_branch + n_trunk + 1
  * host pointers in the order origin_layers.0.., direction_layers.0.., intersection_layers.0.., cat_layers.0,2,..,
  * to_depth.0.  hidden_sizes [n_branch]: widths of the three skip branches (any); cat_sizes [n_trunk]: trunk widths,
@@ -118,12 +128,13 @@ int ns_place_samples(int mode, const float* o_dev, const float* d_dev, const flo
                      float* z_dev, void* stream);
 
 /* ---- a6+a7  Trainer.run_network + NeRF.forward (Trainer.py:789-806, helpers :67-134) --------
- * pts [R,N,3], viewdirs [R,3] -> raw [R,N,4] = (rgb pre-sigmoid, sigma pre-relu).
- * If pts_dev is NULL the points are formed in-kernel as o + d*z from o,d [R,3], z [R,N].     */
+ * pts [R,N,3], viewdirs [R,3] -> raw [R,N,C] = (rgb pre-sigmoid, sigma pre-relu[, ...]), C = ns_nerf_out_channels(net)
+ * (4 for every network with view directions).  viewdirs_dev is ignored (may be NULL) for a network packed with
+ * use_viewdirs == 0.  If pts_dev is NULL the points are formed in-kernel as o + d*z from o,d [R,3], z [R,N].     */
 int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_dev,
                     const float* d_dev, const float* z_dev, const float* viewdirs_dev, int64_t R,
                     int N, float* raw_dev, void* stream);
-/* NeRF.forward on an already embedded input x [M,90] -> [M,4] */
+/* NeRF.forward on an already embedded input x [M,90] (x [M,63] without view directions) -> [M,C] */
 int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t M, float* raw_dev,
                              void* stream);
 
@@ -280,6 +291,9 @@ int ns_add_i32(int* x_dev, int delta, void* stream);
 int ns_event_create(void** ev);
 void ns_event_destroy(void* ev);
 int ns_event_record(void* ev, void* stream);
+/* work submitted to `stream` after this call waits for `ev` (hipStreamWaitEvent): lets a copy stream start a frame
+ * chunk's device-to-host copies exactly when the NEXT chunk's NeRF-MLP kernel starts (ev = its ev_mlp_begin)      */
+int ns_stream_wait_event(void* stream, void* ev);
 /* milliseconds between two recorded events; blocks until `end` has completed */
 int ns_event_elapsed_ms(void* begin, void* end, float* ms);
 

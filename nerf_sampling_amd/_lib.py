@@ -68,6 +68,8 @@ SIGNATURES = {
     "ns_solve_quadratic": (_i, [_p, _p, _p, _i64, _p, _p]),
     "ns_posenc": (_i, [_p, _i64, _i, _i, _p, _p]),
     "ns_pack_nerf": (_i, [_i, _i, _i, _p, _p, _i, C.POINTER(_p)]),
+    "ns_pack_nerf_ex": (_i, [_i, _i, C.c_uint32, _i, _i, _p, _p, _i, C.POINTER(_p)]),
+    "ns_nerf_out_channels": (_i, [_p]),
     "ns_pack_depthnet": (_i, [_i, _i, _p, _p, _i, C.POINTER(_p)]),
     "ns_pack_depthnet_ex": (_i, [_i, _p, _i, _p, _p, _p, _i, C.POINTER(_p)]),
     "ns_fold_depthnet_front": (_i, [_i, _p, _i, _p, _p, _p, _p]),
@@ -102,6 +104,7 @@ SIGNATURES = {
     "ns_event_create": (_i, [C.POINTER(_p)]),
     "ns_event_destroy": (None, [_p]),
     "ns_event_record": (_i, [_p, _p]),
+    "ns_stream_wait_event": (_i, [_p, _p]),
     "ns_event_elapsed_ms": (_i, [_p, _p, C.POINTER(_f)]),
 }
 

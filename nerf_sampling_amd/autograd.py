@@ -144,7 +144,10 @@ class NerfInputGrad(torch.autograd.Function):
         flat = pts.reshape(-1, 3).contiguous()
         dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3).contiguous()
         xe, ve = ops.posenc(flat, 10), ops.posenc(dirs, 4)
-        skip = net._check_supported()
+        skips = net._check_supported()
+        if not net.use_viewdirs:
+            raise NotImplementedError("the input gradient is implemented for networks with view directions (the reference "
+                                      "trains its DepthNet against use_viewdirs=True fields, lego.yaml:11)")
         lins = list(net.pts_linears)
         acts, ins = [], []
         h = xe
@@ -152,7 +155,7 @@ class NerfInputGrad(torch.autograd.Function):
             ins.append(h)
             h = linear_forward(h, lin.weight, lin.bias, RELU)
             acts.append(h)
-            if i == skip:
+            if i in skips:
                 h = torch.cat([xe, h], -1)
         feat = linear_forward(h, net.feature_linear.weight, net.feature_linear.bias)
         vin = torch.cat([feat, ve], -1)
@@ -167,7 +170,7 @@ class NerfInputGrad(torch.autograd.Function):
         d_h = d_h + linear_backward_input(g[:, 3:4].contiguous(), net.alpha_linear.weight)
         d_xe = torch.zeros_like(xe)
         for i in range(len(lins) - 1, -1, -1):
-            if i == skip:                                   # output of layer i was concatenated as cat[xe, h]
+            if i in skips:                                  # output of layer i was concatenated as cat[xe, h]
                 d_xe = d_xe + d_h[:, :63]
                 d_h = d_h[:, 63:].contiguous()
             act_backward_(d_h, acts[i], RELU)

@@ -17,7 +17,9 @@ struct NerfArgs {
   const float* bias;
   uint32_t n_slabs;
   int bias_floats;
-  int D, skip;
+  int D;
+  uint32_t skip_mask;     // bit i: layer i + 1 sees cat[x, h]
+  int use_viewdirs, out_ch, x_stride;   // x_stride: row length of the pre-embedded input (90, or 63 without view directions)
   // inputs: either pts [S,3] or (o,d [R,3], z [S]); or x [S,90] pre-embedded
   const float* pts;
   const float* o;
@@ -59,9 +61,9 @@ nerf_mlp_kernel(NerfArgs a) {
     Block xe[2];  // embedded point (63 -> 64 virtual features)
     Block ve[1];  // embedded view direction (27 -> 32)
     if constexpr (EMBEDDED) {
-      const float* row = a.x90 + s * 90;
+      const float* row = a.x90 + s * a.x_stride;
       gather3<M, 10, 2>(xe, row, h);
-      gather3<M, 4, 1>(ve, row + 63, h);
+      if (a.use_viewdirs) gather3<M, 4, 1>(ve, row + 63, h);
     } else {
       const int64_t ray = s / a.N;
       float p[3], v[3];
@@ -73,10 +75,12 @@ nerf_mlp_kernel(NerfArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) p[c] = a.o[ray * 3 + c] + a.d[ray * 3 + c] * zz;
       }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
       embed3<M, PRECISE_TRIG, 10, 2>(xe, p, h);
-      embed3<M, PRECISE_TRIG, 4, 1>(ve, v, h);
+      if (a.use_viewdirs) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = a.viewdirs[ray * 3 + c];
+        embed3<M, PRECISE_TRIG, 4, 1>(ve, v, h);
+      }
     }
 
     const float* bias = bias_lds;
@@ -89,12 +93,26 @@ nerf_mlp_kernel(NerfArgs a) {
     // layers 1 .. D-1 (the layer after `skip` sees cat[x, h])
     for (int l = 1; l < a.D; ++l) {
       init_bias<NB>(acc, bias, h); bias += NB * 32;
-      if (l - 1 == a.skip) consume<M, NB, 2>(ring, acc, xe);
+      if ((a.skip_mask >> (l - 1)) & 1u) consume<M, NB, 2>(ring, acc, xe);
       consume<M, NB, NB>(ring, acc, hcur);
       to_blocks<M, kRelu, NB>(hcur, acc);
     }
-    // sigma head (W -> 1): row 0 of a 32-row block
     f32x16 acc1[1];
+    if (!a.use_viewdirs) {
+      // output_linear (W -> out_ch, no activation, run_nerf_helpers.py:132-133): rows 0 .. out_ch-1 of one 32-row block;
+      // row (q & 3) + 8 (q >> 2) + 4 h sits in register q of lane half h
+      init_bias<1>(acc1, bias, h);
+      consume<M, 1, NB>(ring, acc1, hcur);
+      if (valid) {
+        static_for<16>([&](auto q_) {
+          constexpr int q = decltype(q_)::value;
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+          if (row < a.out_ch) a.raw[s * a.out_ch + row] = acc1[0][q];
+        });
+      }
+      continue;
+    }
+    // sigma head (W -> 1): row 0 of a 32-row block
     init_bias<1>(acc1, bias, h); bias += 32;
     consume<M, 1, NB>(ring, acc1, hcur);
     const float sigma = acc1[0][0];
@@ -119,13 +137,14 @@ nerf_mlp_kernel(NerfArgs a) {
 }
 
 // number of slabs one pass of the program consumes (must equal ns_weights::n_slabs)
-int nerf_program_slabs(int cpb, int NB, int D, int skip) {
+int nerf_program_slabs(int cpb, int NB, int D, uint32_t skip_mask, int use_viewdirs) {
   int n = seg_slabs(cpb, NB, 2);
   for (int l = 1; l < D; ++l) {
-    if (l - 1 == skip) n += seg_slabs(cpb, NB, 2);
+    if ((skip_mask >> (l - 1)) & 1u) n += seg_slabs(cpb, NB, 2);
     n += seg_slabs(cpb, NB, NB);
   }
-  n += seg_slabs(cpb, 1, NB) + seg_slabs(cpb, NB / 2, NB) + seg_slabs(cpb, NB / 2, 1) + seg_slabs(cpb, 1, NB / 2);
+  if (use_viewdirs) n += seg_slabs(cpb, 1, NB) + seg_slabs(cpb, NB / 2, NB) + seg_slabs(cpb, NB / 2, 1) + seg_slabs(cpb, 1, NB / 2);
+  else n += seg_slabs(cpb, 1, NB);
   return n;
 }
 
@@ -149,9 +168,9 @@ template <bool EMB>
 int dispatch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
   const int NB = net->width / 32;
   const int cpb = net->dtype == NS_DTYPE_F32 ? 4 : 2;
-  if (nerf_program_slabs(cpb, NB, net->depth, net->skip) != static_cast<int>(net->n_slabs)) {
+  if (nerf_program_slabs(cpb, NB, net->depth, net->skip_mask, net->use_viewdirs) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
-                  nerf_program_slabs(cpb, NB, net->depth, net->skip));
+                  nerf_program_slabs(cpb, NB, net->depth, net->skip_mask, net->use_viewdirs));
     return NS_E_INVALID;
   }
   switch (net->dtype) {
@@ -171,22 +190,26 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
 
 extern "C" {
 
+int ns_nerf_out_channels(const ns_weights* net) {
+  return (net && net->kind == NS_KIND_NERF) ? net->out_ch : 0;
+}
+
 int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_dev,
                     const float* d_dev, const float* z_dev, const float* viewdirs_dev, int64_t R,
                     int N, float* raw_dev, void* stream) {
   NS_REQUIRE(net && net->kind == NS_KIND_NERF, "not a NeRF weight handle");
   NS_REQUIRE(R >= 0 && N >= 0, "bad shape");
   if (R == 0 || N == 0) return NS_OK;
-  NS_REQUIRE(raw_dev && viewdirs_dev, "null pointer");
+  NS_REQUIRE(raw_dev && (viewdirs_dev || !net->use_viewdirs), "null pointer");
   NS_REQUIRE(pts_dev || (o_dev && d_dev && z_dev), "need pts or (o, d, z)");
-  NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  NS_REQUIRE(net->out_ch != 4 || (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
                                 ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
-  a.D = net->depth; a.skip = net->skip;
+  a.D = net->depth; a.skip_mask = net->skip_mask; a.use_viewdirs = net->use_viewdirs; a.out_ch = net->out_ch;
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = nullptr;
   a.S = R * N; a.N = N; a.raw = raw_dev;
   return dispatch<false>(net, a, ns::as_stream(stream));
@@ -198,14 +221,15 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
   NS_REQUIRE(M >= 0, "bad shape");
   if (M == 0) return NS_OK;
   NS_REQUIRE(x_dev && raw_dev, "null pointer");
-  NS_REQUIRE((reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
+  NS_REQUIRE(net->out_ch != 4 || (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
                                 ns::as_stream(stream));
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
-  a.D = net->depth; a.skip = net->skip;
+  a.D = net->depth; a.skip_mask = net->skip_mask; a.use_viewdirs = net->use_viewdirs; a.out_ch = net->out_ch;
+  a.x_stride = net->use_viewdirs ? 90 : 63;
   a.x90 = x_dev; a.S = M; a.N = 1; a.raw = raw_dev;
   return dispatch<true>(net, a, ns::as_stream(stream));
 }

@@ -31,7 +31,9 @@ struct Nerf16Args {
   const float* bias;
   uint32_t n_slabs;
   int bias_floats;
-  int D, skip;
+  int D;
+  uint32_t skip_mask;     // bit i: layer i + 1 sees cat[x, h]
+  int use_viewdirs, out_ch, x_stride;   // x_stride: row length of the pre-embedded input (90, or 63 without view directions)
   // inputs: either pts [S,3] or (o,d [R,3], z [S]); or x [S,90] pre-embedded
   const float* pts;
   const float* o;
@@ -104,8 +106,10 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
       put(6, a.z + sidx);
     }
+    if (a.use_viewdirs) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+      for (int c = 0; c < 3; ++c) put(7 + c, a.viewdirs + ray * 3 + c);
+    }
   };
   auto prefetch = [&](int64_t grp) {
     if constexpr (!EMBEDDED) {
@@ -133,11 +137,14 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       Block ve[1];    // embedded view direction (27 -> 32)
       if constexpr (EMBEDDED) {
         bool valid;
-        const float* row = a.x90 + sample_of(grp, t, n, valid) * 90;
+        const float* row = a.x90 + sample_of(grp, t, n, valid) * a.x_stride;
         gather3_16<M, 10, 2>(xe[t], row, g);
-        gather3_16<M, 4, 1>(ve, row + 63, g);
-        if (!(finite(row[0]) && finite(row[1]) && finite(row[2]) && finite(row[63]) && finite(row[64]) && finite(row[65])))
-          bad |= 1u << t;
+        bool ok = finite(row[0]) && finite(row[1]) && finite(row[2]);
+        if (a.use_viewdirs) {
+          gather3_16<M, 4, 1>(ve, row + 63, g);
+          ok = ok && finite(row[63]) && finite(row[64]) && finite(row[65]);
+        }
+        if (!ok) bad |= 1u << t;
       } else {
         float p[3], v[3];
         if (a.pts) {
@@ -148,13 +155,18 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) p[c] = staged(t, c) + staged(t, 3 + c) * zz;
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
-        if (!(finite(p[0]) && finite(p[1]) && finite(p[2]) && finite(v[0]) && finite(v[1]) && finite(v[2]))) bad |= 1u << t;
+        bool ok = finite(p[0]) && finite(p[1]) && finite(p[2]);
         embed3_16<M, false, 10, 2>(xe[t], p[0], p[1], p[2], g);
-        embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
+        if (a.use_viewdirs) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
+          ok = ok && finite(v[0]) && finite(v[1]) && finite(v[2]);
+          embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
+        }
+        if (!ok) bad |= 1u << t;
       }
-      stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, ve[0]);
+      stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]);
+      if (a.use_viewdirs) stash_put(t, 2, ve[0]);
     });
 
     const float* bias = bias_lds;
@@ -202,18 +214,34 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     int l = 1;
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     for (; l + 1 < a.D; l += 2) {
-      if (l - 1 == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
+      if ((a.skip_mask >> (l - 1)) & 1u) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
-      if (l == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB); }
+      if ((a.skip_mask >> l) & 1u) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hA, last, in_xB); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hA, last, in_B);
       convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
     }
     if (l < a.D) {  // odd layer left over: hA -> hB, then move back
-      if (l - 1 == a.skip) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
+      if ((a.skip_mask >> (l - 1)) & 1u) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
+    }
+    if (!a.use_viewdirs) {
+      // output_linear (W -> out_ch, no activation, run_nerf_helpers.py:132-133): ONE 16-row sub-block whose raw accumulators
+      // come back in `last`: row 4 g + r sits in register r of lane group g
+      layer_ob16<M, T, 1, NKB, kNone>(ring, bias, g, hB, last, in_A);
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        bool valid;
+        const int64_t sidx = sample_of(grp, t, n, valid);
+        static_for<4>([&](auto r_) {
+          constexpr int r = decltype(r_)::value;
+          const int row = 4 * g + r;
+          if (valid && row < a.out_ch) a.raw[sidx * a.out_ch + row] = ((bad >> t) & 1u) ? __builtin_nanf("") : last[t][r];
+        });
+      });
+      continue;
     }
     // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
     // cat[h, dirs27] -> W/2, relu: (hA, ve) -> hB[0 .. NKB/2); alpha_linear rides along as row 0 of one extra, LAST
@@ -251,11 +279,12 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   ring.finish();
 }
 
-int ob16_program_slabs(int W, int D, int skip) {
+int ob16_program_slabs(int W, int D, uint32_t skip_mask, int use_viewdirs) {
   const int NSB = W / 16, NKB = W / 32, dp = kOb16Depth;
   int n = ob16_layer_slabs(NSB, 2, dp);
-  for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, (l - 1 == skip) ? NKB + 2 : NKB, dp);
-  n += ob16_layer_slabs(NSB / 2 + 1, NKB + 1, dp) + ob16_layer_slabs(1, NKB / 2, dp);
+  for (int l = 1; l < D; ++l) n += ob16_layer_slabs(NSB, ((skip_mask >> (l - 1)) & 1u) ? NKB + 2 : NKB, dp);
+  if (use_viewdirs) n += ob16_layer_slabs(NSB / 2 + 1, NKB + 1, dp) + ob16_layer_slabs(1, NKB / 2, dp);
+  else n += ob16_layer_slabs(1, NKB, dp);
   return n;
 }
 
@@ -297,15 +326,16 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
                          float* raw_dev, hipStream_t stream) {
   if (net->dtype == NS_DTYPE_F16X3)   // split fp16 operands: ns_nerf_mlp_x3.hip
     return ns_nerf_forward_x3(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, x90_dev, S, N, raw_dev, stream);
-  if (ob16_program_slabs(net->width, net->depth, net->skip) != static_cast<int>(net->n_slabs)) {
+  if (ob16_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
-                  ob16_program_slabs(net->width, net->depth, net->skip));
+                  ob16_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs));
     return NS_E_INVALID;
   }
   Nerf16Args a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
-  a.D = net->depth; a.skip = net->skip;
+  a.D = net->depth; a.skip_mask = net->skip_mask; a.use_viewdirs = net->use_viewdirs; a.out_ch = net->out_ch;
+  a.x_stride = net->use_viewdirs ? 90 : 63;
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
   const bool emb = x90_dev != nullptr;

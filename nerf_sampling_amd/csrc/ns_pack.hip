@@ -309,20 +309,37 @@ extern "C" {
 
 int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* const* b, int dtype,
                  ns_weights** out) {
-  NS_REQUIRE(out && w && b, "null pointer");
-  *out = nullptr;
-  if (!(W == 128 || W == 256) || D < 1 || D > 64 || skip < -1 || (skip >= 0 && skip >= D - 1) ||
-      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
-    ns::set_error("ns_pack_nerf: unsupported network (W=%d D=%d skip=%d dtype=%d); kernels exist for "
-                  "W in {128,256}, one optional skip before the last layer, input_ch 63/27", W, D, skip, dtype);
+  if (skip < -1 || skip >= 32 || (skip >= 0 && skip >= D - 1)) {
+    ns::set_error("ns_pack_nerf: unsupported network (D=%d skip=%d): the skip must precede the last layer", D, skip);
+    if (out) *out = nullptr;
     return NS_E_UNSUPPORTED;
   }
-  for (int i = 0; i < D + 4; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
+  return ns_pack_nerf_ex(D, W, skip >= 0 ? (1u << skip) : 0u, 1, 4, w, b, dtype, out);
+}
+
+int ns_pack_nerf_ex(int D, int W, uint32_t skip_mask, int use_viewdirs, int output_ch, const float* const* w,
+                    const float* const* b, int dtype, ns_weights** out) {
+  NS_REQUIRE(out && w && b, "null pointer");
+  *out = nullptr;
+  const int out_ch = use_viewdirs ? 4 : output_ch;
+  if (!(W == 128 || W == 256) || D < 1 || D > 32 || (D < 32 && (skip_mask >> (D - 1)) != 0) || out_ch < 1 || out_ch > 16 ||
+      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
+    ns::set_error("ns_pack_nerf: unsupported network (W=%d D=%d skips=0x%x output_ch=%d dtype=%d); kernels exist for "
+                  "W in {128,256}, D <= 32, skips before the last layer, input_ch 63 (/27), output_ch <= 16", W, D, skip_mask,
+                  out_ch, dtype);
+    return NS_E_UNSUPPORTED;
+  }
+  auto skipped = [skip_mask](int l) { return l >= 1 && ((skip_mask >> (l - 1)) & 1u) != 0; };   // layer l sees cat[x, h]
+  const int n_tensors = use_viewdirs ? D + 4 : D + 1;
+  for (int i = 0; i < n_tensors; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
   if (dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) {   // fp16 operands: refuse what would silently become +-inf
     bool ok = true;
-    for (int l = 0; l < D && ok; ++l) ok = fits_f16(w[l], static_cast<size_t>(W) * (l == 0 ? 63 : (l - 1 == skip ? W + 63 : W)));
-    ok = ok && fits_f16(w[D], static_cast<size_t>(W) * W) && fits_f16(w[D + 1], W) &&
-         fits_f16(w[D + 2], static_cast<size_t>(W / 2) * (W + 27)) && fits_f16(w[D + 3], static_cast<size_t>(3) * (W / 2));
+    for (int l = 0; l < D && ok; ++l) ok = fits_f16(w[l], static_cast<size_t>(W) * (l == 0 ? 63 : (skipped(l) ? W + 63 : W)));
+    if (use_viewdirs)
+      ok = ok && fits_f16(w[D], static_cast<size_t>(W) * W) && fits_f16(w[D + 1], W) &&
+           fits_f16(w[D + 2], static_cast<size_t>(W / 2) * (W + 27)) && fits_f16(w[D + 3], static_cast<size_t>(3) * (W / 2));
+    else
+      ok = ok && fits_f16(w[D], static_cast<size_t>(out_ch) * W);
     if (!ok) {
       ns::set_error("ns_pack_nerf: a weight exceeds fp16's range (65504); use bf16 or f32 operands for this network");
       return NS_E_UNSUPPORTED;
@@ -335,10 +352,12 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
   const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;   // 0 = k-major (fp32 kernel); 16 = 16x16x32 engine (bf16 / f16)
   const int HV = W / 2, KV = W + 27;
   std::vector<float> wvf, bvf;
-  fold_nerf_views(W, w[D], b[D], w[D + 2], b[D + 2], wvf, bvf);
-  if ((dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) && !fits_f16(wvf.data(), wvf.size())) {
-    ns::set_error("ns_pack_nerf: a folded views-layer weight exceeds fp16's range (65504); use bf16 or f32 operands");
-    return NS_E_UNSUPPORTED;
+  if (use_viewdirs) {
+    fold_nerf_views(W, w[D], b[D], w[D + 2], b[D + 2], wvf, bvf);
+    if ((dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) && !fits_f16(wvf.data(), wvf.size())) {
+      ns::set_error("ns_pack_nerf: a folded views-layer weight exceeds fp16's range (65504); use bf16 or f32 operands");
+      return NS_E_UNSUPPORTED;
+    }
   }
   if (layout == 0) {
     // layer 0: 63 -> W
@@ -346,7 +365,7 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     bl.segment(w[0], W, 63, NB, 2, xcol);
     for (int l = 1; l < D; ++l) {
       bl.add_bias(b[l], W, NB);
-      if (l - 1 == skip) {  // input = cat[x(63), h(W)]  (run_nerf_helpers.py:118)
+      if (skipped(l)) {  // input = cat[x(63), h(W)]  (run_nerf_helpers.py:118)
         bl.segment(w[l], W, W + 63, NB, 2, xcol);
         bl.segment(w[l], W, W + 63, NB, NB, [](int k) { return 63 + k; });
       } else {
@@ -355,14 +374,20 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     }
     const float* const* wf = w + D;
     const float* const* bf = b + D;
-    // alpha (W -> 1), views o feature folded ([h, dirs27] -> W/2), rgb (W/2 -> 3)
-    bl.add_bias(bf[1], 1, 1);
-    bl.segment(wf[1], 1, W, 1, NB, ident);
-    bl.add_bias(bvf.data(), HV, NB / 2);
-    bl.segment(wvf.data(), HV, KV, NB / 2, NB, ident);
-    bl.segment(wvf.data(), HV, KV, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
-    bl.add_bias(bf[3], 3, 1);
-    bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
+    if (use_viewdirs) {
+      // alpha (W -> 1), views o feature folded ([h, dirs27] -> W/2), rgb (W/2 -> 3)
+      bl.add_bias(bf[1], 1, 1);
+      bl.segment(wf[1], 1, W, 1, NB, ident);
+      bl.add_bias(bvf.data(), HV, NB / 2);
+      bl.segment(wvf.data(), HV, KV, NB / 2, NB, ident);
+      bl.segment(wvf.data(), HV, KV, NB / 2, 1, [W](int k) { const int c = nsmlp::embed3_col(k, 4); return c < 0 ? -1 : W + c; });
+      bl.add_bias(bf[3], 3, 1);
+      bl.segment(wf[3], 3, W / 2, 1, NB / 2, ident);
+    } else {
+      // output_linear (W -> output_ch), no activation (run_nerf_helpers.py:132-133): rows 0 .. out_ch-1 of one block
+      bl.add_bias(bf[0], out_ch, 1);
+      bl.segment(wf[0], out_ch, W, 1, NB, ident);
+    }
   } else if (layout == 16) {
     // same layers for the 16x16x32 kernel (ns_nerf_mlp_ob16.hip): NSB = out/16 sub-blocks, K-blocks of 32 features;
     // hidden features arrive in feature16() order, i.e. plain feature indices for the column maps
@@ -373,29 +398,35 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
     bl.layer_ob16(w[0], W, 63, NSB, {{2, xcol16}});
     for (int l = 1; l < D; ++l) {
       bl.add_bias16(b[l], W, NSB);
-      if (l - 1 == skip) bl.layer_ob16(w[l], W, W + 63, NSB, {{2, xcol16}, {NKB, hcol}});
+      if (skipped(l)) bl.layer_ob16(w[l], W, W + 63, NSB, {{2, xcol16}, {NKB, hcol}});
       else bl.layer_ob16(w[l], W, W, NSB, {{NKB, ident}});
     }
     const float* const* wf = w + D;
-    const float* const* bf = b + D;
-    // views o feature (folded) with alpha_linear riding along as row W/2, i.e. row 0 of one extra 16-row sub-block
-    // whose raw accumulators the kernel reads as sigma (no activation: it is the layer's LAST sub-block)
-    (void)bf;
-    std::vector<float> wc(static_cast<size_t>(HV + 1) * KV, 0.0f), bc(HV + 1, 0.0f);
-    std::memcpy(wc.data(), wvf.data(), wvf.size() * sizeof(float));
-    std::memcpy(bc.data(), bvf.data(), bvf.size() * sizeof(float));
-    std::memcpy(wc.data() + static_cast<size_t>(HV) * KV, wf[1], static_cast<size_t>(W) * sizeof(float));
-    bc[HV] = b[D + 1][0];
-    bl.add_bias16(bc.data(), HV + 1, NSB / 2 + 1);
-    bl.layer_ob16(wc.data(), HV + 1, KV, NSB / 2 + 1,
-                  {{NKB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col16(k, 4); return c < 0 ? -1 : W + c; }}});
-    bl.add_bias16(b[D + 3], 3, 1);
-    bl.layer_ob16(wf[3], 3, W / 2, 1, {{NKB / 2, ident}});
+    if (use_viewdirs) {
+      // views o feature (folded) with alpha_linear riding along as row W/2, i.e. row 0 of one extra 16-row sub-block
+      // whose raw accumulators the kernel reads as sigma (no activation: it is the layer's LAST sub-block)
+      std::vector<float> wc(static_cast<size_t>(HV + 1) * KV, 0.0f), bc(HV + 1, 0.0f);
+      std::memcpy(wc.data(), wvf.data(), wvf.size() * sizeof(float));
+      std::memcpy(bc.data(), bvf.data(), bvf.size() * sizeof(float));
+      std::memcpy(wc.data() + static_cast<size_t>(HV) * KV, wf[1], static_cast<size_t>(W) * sizeof(float));
+      bc[HV] = b[D + 1][0];
+      bl.add_bias16(bc.data(), HV + 1, NSB / 2 + 1);
+      bl.layer_ob16(wc.data(), HV + 1, KV, NSB / 2 + 1,
+                    {{NKB, ident}, {1, [W](int k) { const int c = nsmlp::embed3_col16(k, 4); return c < 0 ? -1 : W + c; }}});
+      bl.add_bias16(b[D + 3], 3, 1);
+      bl.layer_ob16(wf[3], 3, W / 2, 1, {{NKB / 2, ident}});
+    } else {
+      bl.add_bias16(b[D], out_ch, 1);
+      bl.layer_ob16(wf[0], out_ch, W, 1, {{NKB, ident}});
+    }
   }
 
   ns_weights* h = new ns_weights();
   std::memset(h, 0, sizeof(*h));
-  h->kind = NS_KIND_NERF; h->dtype = dtype; h->width = W; h->depth = D; h->skip = skip; h->layout = layout;
+  h->kind = NS_KIND_NERF; h->dtype = dtype; h->width = W; h->depth = D; h->layout = layout;
+  h->skip_mask = skip_mask; h->use_viewdirs = use_viewdirs ? 1 : 0; h->out_ch = out_ch;
+  h->skip = -1;
+  for (int i = 0; i < 32; ++i) if ((skip_mask >> i) & 1u) { h->skip = i; break; }
   int rc = finish(bl, h);
   if (rc != NS_OK) { ns_weights_destroy(h); return rc; }
   *out = h;

@@ -36,6 +36,8 @@ int64_t ns_render_workspace_bytes(int64_t R, int N) {
 int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   NS_REQUIRE(a, "null args");
   NS_REQUIRE(a->depthnet && a->nerf, "both networks are required");
+  NS_REQUIRE(a->nerf->kind == NS_KIND_NERF && a->nerf->out_ch == 4 && a->nerf->use_viewdirs,
+             "the one-call path composites raw [R,N,4] of a network with view directions");
   if (a->o_dev == nullptr ? (a->row1 == a->row0 || a->W == 0) : a->R == 0) return NS_OK;  // nothing to render
   if (a->o_dev == nullptr && a->H == 0 && a->R == 0) return NS_OK;
   NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
@@ -91,6 +93,8 @@ int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf) {
 
 int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   NS_REQUIRE(a && a->coarse, "null args / coarse network");
+  NS_REQUIRE(a->coarse->out_ch == 4 && a->coarse->use_viewdirs && (!a->fine || (a->fine->out_ch == 4 && a->fine->use_viewdirs)),
+             "the one-call path composites raw [R,N,4] of networks with view directions");
   if (a->o_dev == nullptr ? (a->row1 == a->row0 || a->W == 0) : a->R == 0) return NS_OK;  // nothing to render
   NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
   NS_REQUIRE(a->Nc >= 3 && a->Nf >= 0, "needs at least 3 coarse samples");
@@ -160,6 +164,12 @@ void ns_event_destroy(void* ev) {
 int ns_event_record(void* ev, void* stream) {
   NS_REQUIRE(ev, "null event");
   NS_HIP(hipEventRecord(static_cast<hipEvent_t>(ev), ns::as_stream(stream)));
+  return NS_OK;
+}
+
+int ns_stream_wait_event(void* stream, void* ev) {
+  NS_REQUIRE(ev, "null event");
+  NS_HIP(hipStreamWaitEvent(ns::as_stream(stream), static_cast<hipEvent_t>(ev), 0));
   return NS_OK;
 }
 

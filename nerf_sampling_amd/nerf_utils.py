@@ -352,7 +352,7 @@ def _one_call_eligible(depth_network, net, network_query_fn, trainer, viewdirs) 
     from .trainers import DepthNetTrainer
 
     return (viewdirs is not None and getattr(network_query_fn, "_ns_standard_query", False)
-            and isinstance(depth_network, DepthNet) and isinstance(net, run_nerf_helpers.NeRF)
+            and isinstance(depth_network, DepthNet) and isinstance(net, run_nerf_helpers.NeRF) and net.use_viewdirs
             and type(trainer).raw2outputs is DepthNetTrainer.raw2outputs
             and type(trainer).run_network is DepthNetTrainer.run_network
             and trainer.sampling_mode in ("uniform", "gaussian", "depth_only")

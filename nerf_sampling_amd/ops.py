@@ -140,17 +140,30 @@ def _host_ptr_array(tensors: Sequence[Tensor]):
     return arr, keep
 
 
-def pack_nerf(weights: Sequence[Tensor], biases: Sequence[Tensor], D: int, W: int, skip: int,
-              dtype: Optional[str] = None, device="cuda") -> PackedWeights:
-    """weights/biases in the order pts_linears.0..D-1, feature_linear, alpha_linear, views_linears.0, rgb_linear."""
+def pack_nerf(weights: Sequence[Tensor], biases: Sequence[Tensor], D: int, W: int, skip,
+              dtype: Optional[str] = None, device="cuda", use_viewdirs: bool = True, output_ch: int = 4) -> PackedWeights:
+    """weights/biases in the order pts_linears.0..D-1, then feature_linear, alpha_linear, views_linears.0, rgb_linear
+    (use_viewdirs) or output_linear (use_viewdirs=False: raw has ``output_ch`` channels).  ``skip``: the reference's
+    ``skips`` list (or one index / -1): layer i + 1 sees cat[x, h] for every i in it."""
     lib = _lib.load()
+    skips = [skip] if isinstance(skip, int) else list(skip)
+    skips = [int(i) for i in skips if int(i) >= 0]
+    if any(i >= 32 for i in skips):
+        raise NotImplementedError("skip indices beyond 31 are not supported")
+    mask = 0
+    for i in skips:
+        mask |= 1 << i
     wa, k1 = _host_ptr_array(weights)
     ba, k2 = _host_ptr_array(biases)
     out = C.c_void_p()
     name = dtype or _compute_dtype
     with torch.cuda.device(device):
-        check(lib.ns_pack_nerf(D, W, skip, wa, ba, dtype_code(name), C.byref(out)), "ns_pack_nerf")
-    return PackedWeights(out.value, "nerf", name, torch.device(device))
+        check(lib.ns_pack_nerf_ex(D, W, mask, int(bool(use_viewdirs)), int(output_ch), wa, ba, dtype_code(name),
+                                  C.byref(out)), "ns_pack_nerf_ex")
+    pw = PackedWeights(out.value, "nerf", name, torch.device(device))
+    pw.out_ch = int(lib.ns_nerf_out_channels(pw.handle))
+    pw.use_viewdirs = bool(use_viewdirs)
+    return pw
 
 
 def pack_depthnet(weights: Sequence[Tensor], biases: Sequence[Tensor], hidden_sizes: Sequence[int],
@@ -218,23 +231,28 @@ def points_along_rays(o: Tensor, d: Tensor, z: Tensor) -> Tensor:
 
 
 # ---- a6 / a7 ----------------------------------------------------------------------------------------
-def nerf_forward(net: PackedWeights, pts: Tensor, viewdirs: Tensor) -> Tensor:
-    """pts [R,N,3], viewdirs [R,3] -> raw [R,N,4]"""
+def nerf_forward(net: PackedWeights, pts: Tensor, viewdirs: Optional[Tensor]) -> Tensor:
+    """pts [R,N,3], viewdirs [R,3] (None for a network without view directions) -> raw [R,N,C], C = net.out_ch"""
     lib = _lib.load()
-    pts, viewdirs = _dev(pts, "pts"), _dev(viewdirs, "viewdirs")
+    pts = _dev(pts, "pts")
+    if getattr(net, "use_viewdirs", True):
+        viewdirs = _dev(viewdirs, "viewdirs")
+    else:
+        viewdirs = None
     R, N = pts.shape[0], pts.shape[1]
-    raw = torch.empty((R, N, 4), dtype=torch.float32, device=pts.device)
+    raw = torch.empty((R, N, getattr(net, "out_ch", 4)), dtype=torch.float32, device=pts.device)
     check(lib.ns_nerf_forward(net.handle, _ptr(pts), None, None, None, _ptr(viewdirs), R, N, _ptr(raw),
                               _stream(pts.device)), "ns_nerf_forward")
     return raw
 
 
-def nerf_forward_rays(net: PackedWeights, o: Tensor, d: Tensor, z: Tensor, viewdirs: Tensor) -> Tensor:
-    """points formed in-kernel as o + d*z; z [R,N] -> raw [R,N,4]"""
+def nerf_forward_rays(net: PackedWeights, o: Tensor, d: Tensor, z: Tensor, viewdirs: Optional[Tensor]) -> Tensor:
+    """points formed in-kernel as o + d*z; z [R,N] -> raw [R,N,C]"""
     lib = _lib.load()
-    o, d, z, viewdirs = _dev(o, "rays_o"), _dev(d, "rays_d"), _dev(z, "z"), _dev(viewdirs, "viewdirs")
+    o, d, z = _dev(o, "rays_o"), _dev(d, "rays_d"), _dev(z, "z")
+    viewdirs = _dev(viewdirs, "viewdirs") if getattr(net, "use_viewdirs", True) else None
     R, N = z.shape
-    raw = torch.empty((R, N, 4), dtype=torch.float32, device=z.device)
+    raw = torch.empty((R, N, getattr(net, "out_ch", 4)), dtype=torch.float32, device=z.device)
     check(lib.ns_nerf_forward(net.handle, None, _ptr(o), _ptr(d), _ptr(z), _ptr(viewdirs), R, N, _ptr(raw),
                               _stream(z.device)), "ns_nerf_forward")
     return raw
@@ -243,10 +261,11 @@ def nerf_forward_rays(net: PackedWeights, o: Tensor, d: Tensor, z: Tensor, viewd
 def nerf_forward_embedded(net: PackedWeights, x: Tensor) -> Tensor:
     lib = _lib.load()
     x = _dev(x, "x")
-    if x.shape[-1] != 90:
-        raise NotImplementedError(f"embedded input must be 63+27=90 wide, got {x.shape[-1]}")
-    M = x.numel() // 90
-    raw = torch.empty(tuple(x.shape[:-1]) + (4,), dtype=torch.float32, device=x.device)
+    width = 90 if getattr(net, "use_viewdirs", True) else 63
+    if x.shape[-1] != width:
+        raise NotImplementedError(f"embedded input must be {width} wide (63 point + 27 direction features), got {x.shape[-1]}")
+    M = x.numel() // width
+    raw = torch.empty(tuple(x.shape[:-1]) + (getattr(net, "out_ch", 4),), dtype=torch.float32, device=x.device)
     check(lib.ns_nerf_forward_embedded(net.handle, _ptr(x), M, _ptr(raw), _stream(x.device)),
           "ns_nerf_forward_embedded")
     return raw
@@ -257,6 +276,8 @@ def raw2outputs(raw: Tensor, z: Tensor, rays_d: Tensor, noise: Optional[Tensor] 
                 white_bkgd: bool = True, want_per_sample: bool = True):
     """-> rgb [R,3], disp [R], acc [R], depth [R], alphas [R,N] | None, weights [R,N] | None"""
     lib = _lib.load()
+    if raw.shape[-1] > 4:        # output_ch = 5 networks (no view directions, N_importance > 0): channel 4 is never read
+        raw = raw[..., :4]
     raw, z, rays_d = _dev(raw, "raw"), _dev(z, "z_vals"), _dev(rays_d, "rays_d")
     R, N = z.shape
     dev = raw.device

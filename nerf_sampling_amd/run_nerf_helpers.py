@@ -81,25 +81,29 @@ class NeRF(nn.Module):
 
     # -- packing ---------------------------------------------------------------------------------
     def _check_supported(self):
-        if not self.use_viewdirs:
-            raise NotImplementedError("the HIP kernel implements the use_viewdirs=True architecture only")
-        if self.input_ch != 63 or self.input_ch_views != 27:
+        """The HIP kernels cover the reference's whole constructor (run_nerf_helpers.py:67-105) for W in {128, 256}: any
+        D <= 32, any ``skips`` list, both heads (use_viewdirs True / False with output_linear).  Returns the active skips."""
+        if self.input_ch != 63 or (self.use_viewdirs and self.input_ch_views != 27):
             raise NotImplementedError("the HIP kernel is built for multires=10 / multires_views=4 (63+27 inputs)")
-        active = [s for s in self.skips if s < self.D - 1]
-        if len(active) > 1:
-            raise NotImplementedError("at most one skip connection is supported")
-        return active[0] if active else -1
+        if self.W not in (128, 256):
+            raise NotImplementedError(f"the HIP kernels are built for W in (128, 256), got {self.W}")
+        return sorted({int(s_) for s_ in self.skips if 0 <= int(s_) < self.D - 1})
+
+    @property
+    def output_channels(self) -> int:
+        return 4 if self.use_viewdirs else self.output_linear.out_features
 
     def packed(self, dtype: Optional[str] = None) -> ops.PackedWeights:
         """Device weight stream for the MFMA kernels (cached per dtype; call ``repack`` after updates)."""
         name = dtype or ops.get_compute_dtype()
         if name not in self._packed:
-            skip = self._check_supported()
-            mods = list(self.pts_linears) + [self.feature_linear, self.alpha_linear, self.views_linears[0],
-                                             self.rgb_linear]
+            skips = self._check_supported()
+            mods = list(self.pts_linears) + ([self.feature_linear, self.alpha_linear, self.views_linears[0], self.rgb_linear]
+                                             if self.use_viewdirs else [self.output_linear])
             dev = self.pts_linears[0].weight.device
-            self._packed[name] = ops.pack_nerf([m.weight for m in mods], [m.bias for m in mods], self.D, self.W,
-                                               skip, name, dev if dev.type == "cuda" else "cuda")
+            self._packed[name] = ops.pack_nerf([m.weight for m in mods], [m.bias for m in mods], self.D, self.W, skips, name,
+                                               dev if dev.type == "cuda" else "cuda", use_viewdirs=self.use_viewdirs,
+                                               output_ch=self.output_channels)
         return self._packed[name]
 
     def repack(self):

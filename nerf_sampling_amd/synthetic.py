@@ -71,7 +71,7 @@ def _decay_embedding_columns(w: Tensor, start: int, d: int, n_freqs: int) -> Non
 def make_nerf_params(
     seed: int, D: int = 8, W: int = 256, input_ch: int = 63, input_ch_views: int = 27,
     skips=(4,), sigma_gain: float = 1.0, sigma_bias: float = 0.0, hidden_gain: float = 1.0,
-    spectral_decay: bool = False,
+    spectral_decay: bool = False, use_viewdirs: bool = True, output_ch: int = 4,
 ) -> Params:
     """Deterministic NeRF weights, nn.Linear-default-like U(+-1/sqrt(fan_in)) scale.
 
@@ -87,10 +87,14 @@ def make_nerf_params(
         if spectral_decay and in_f != W:  # layers that see the embedded point (first 63 columns)
             _decay_embedding_columns(w, 0, 3, (input_ch // 3 - 1) // 2)
         p[f"pts_linears.{i}.weight"], p[f"pts_linears.{i}.bias"] = w, b
-    w, b = _uniform_linear(rng, W // 2, input_ch_views + W, hidden_gain)
+    w, b = _uniform_linear(rng, W // 2, input_ch_views + W, hidden_gain)   # views_linears exists in both variants (:94)
     if spectral_decay:
         _decay_embedding_columns(w, W, 3, (input_ch_views // 3 - 1) // 2)
     p["views_linears.0.weight"], p["views_linears.0.bias"] = w, b
+    if not use_viewdirs:       # run_nerf_helpers.py:104-105
+        w, b = _uniform_linear(rng, output_ch, W, hidden_gain)
+        p["output_linear.weight"], p["output_linear.bias"] = w, b
+        return p
     w, b = _uniform_linear(rng, W, W, hidden_gain)
     p["feature_linear.weight"], p["feature_linear.bias"] = w, b
     w, b = _uniform_linear(rng, 1, W)
@@ -170,6 +174,17 @@ def make_depthnet_params_shaped(seed: int, hidden_sizes, cat_hidden_sizes, multi
 
 
 SQRT3, SQRT6 = math.sqrt(3.0), math.sqrt(6.0)
+
+# NeRF constructor variants beyond the production one (run_nerf_helpers.py:67-105), pinned against the reference by
+# tests/golden/nerf_variants.npz: tag -> make_nerf_params kwargs (+ the constructor's own arguments)
+NERF_VARIANTS = {
+    "two_skips": dict(seed=81, D=6, W=128, skips=(1, 3), use_viewdirs=True, hidden_gain=SQRT6, spectral_decay=True),
+    "skip_first_and_late": dict(seed=82, D=7, W=256, skips=(0, 2, 5), use_viewdirs=True, hidden_gain=SQRT6, spectral_decay=True),
+    "no_viewdirs_5ch": dict(seed=83, D=5, W=128, skips=(2,), use_viewdirs=False, output_ch=5, input_ch_views=0,
+                            hidden_gain=SQRT6, spectral_decay=True),
+    "no_viewdirs_4ch": dict(seed=84, D=3, W=256, skips=(), use_viewdirs=False, output_ch=4, input_ch_views=0,
+                            hidden_gain=SQRT6, spectral_decay=True),
+}
 
 # DepthNet shapes other than one uniform width, pinned against the reference by tests/golden/depthnet_shapes.npz:
 # tag -> (hidden_sizes, cat_hidden_sizes, seed).  "default" is the reference's class default (depth_net.py:13-16).

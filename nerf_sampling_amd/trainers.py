@@ -57,9 +57,13 @@ class Trainer:
         With this package's NeRF module and 10/4-frequency embedders the whole operator is one
         MFMA kernel (no [R*N,90] embedding in memory, no netchunk loop).
         """
-        fused = (isinstance(fn, NeRF) and isinstance(embed_fn, Embedder) and isinstance(embeddirs_fn, Embedder)
-                 and viewdirs is not None and embed_fn.num_freqs == 10 and embeddirs_fn.num_freqs == 4
-                 and embed_fn.input_dims == 3 and embeddirs_fn.input_dims == 3)
+        fused = (isinstance(fn, NeRF) and isinstance(embed_fn, Embedder) and embed_fn.num_freqs == 10
+                 and embed_fn.input_dims == 3)
+        if fused and fn.use_viewdirs:
+            fused = (viewdirs is not None and isinstance(embeddirs_fn, Embedder) and embeddirs_fn.num_freqs == 4
+                     and embeddirs_fn.input_dims == 3)
+        elif fused:                       # output_linear head: the reference feeds the 63 point features only
+            fused = viewdirs is None
         if fused:
             if torch.is_grad_enabled() and inputs.requires_grad:   # training: gradient w.r.t. the points only
                 from .autograd import NerfInputGrad

@@ -207,13 +207,16 @@ def nerf_depth(p: Params) -> int:
 
 
 def nerf_forward(p: Params, x: Tensor, input_ch: int = 63, skips=(4,)) -> Tensor:
-    """[M, input_ch + input_ch_views] -> [M, 4] raw (rgb pre-sigmoid, sigma pre-relu)."""
+    """[M, input_ch + input_ch_views] -> [M, 4] raw (rgb pre-sigmoid, sigma pre-relu); a state dict with an
+    ``output_linear`` (use_viewdirs=False, run_nerf_helpers.py:132-133) -> [M, output_ch]."""
     pts, views = x[..., :input_ch], x[..., input_ch:]
     h = pts
     for i in range(nerf_depth(p)):
         h = torch.relu(_lin(p, f"pts_linears.{i}", h))
         if i in skips:
             h = torch.cat([pts, h], -1)  # input first, hidden second (:118)
+    if "output_linear.weight" in p:
+        return _lin(p, "output_linear", h)
     sigma = _lin(p, "alpha_linear", h)
     feat = _lin(p, "feature_linear", h)  # no relu (:121)
     h = torch.relu(_lin(p, "views_linears.0", torch.cat([feat, views], -1)))
@@ -228,6 +231,7 @@ def run_network(
     multires: int = 10,
     multires_views: int = 4,
     netchunk: int = 1024 * 64,
+    skips=(4,),
 ) -> Tensor:
     """Embed + MLP in netchunk-row slices; [R,N,3] -> [R,N,4] (Trainer.py:789-806)."""
     flat = pts.reshape(-1, pts.shape[-1])
@@ -237,7 +241,7 @@ def run_network(
         emb = torch.cat([emb, posenc(dirs, multires_views)], -1)
     in_ch = posenc_dim(pts.shape[-1], multires)
     outs = [
-        nerf_forward(p, emb[i : i + netchunk], in_ch) for i in range(0, emb.shape[0], netchunk)
+        nerf_forward(p, emb[i : i + netchunk], in_ch, skips) for i in range(0, emb.shape[0], netchunk)
     ]
     out = torch.cat(outs, 0)
     return out.reshape(list(pts.shape[:-1]) + [out.shape[-1]])

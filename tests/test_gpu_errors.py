@@ -28,9 +28,13 @@ def test_unsupported_network_shapes_raise():
     net = NeRF(D=8, W=96, input_ch=63, input_ch_views=27, use_viewdirs=True).cuda()   # width without a kernel
     with pytest.raises(NotImplementedError):
         net(torch.zeros(8, 90).cuda())
-    net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=False).cuda()
+    net = NeRF(D=8, W=256, input_ch=21, input_ch_views=27, use_viewdirs=True).cuda()   # not the multires the kernel embeds
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(8, 48).cuda())
+    net = NeRF(D=8, W=256, input_ch=63, input_ch_views=0, use_viewdirs=False).cuda()    # output_linear head: 63 features in
     with pytest.raises(NotImplementedError):
         net(torch.zeros(8, 90).cuda())
+    assert net(torch.zeros(8, 63).cuda()).shape == (8, 4)
 
 
 def test_fp16_operand_range_is_checked_at_pack_time():

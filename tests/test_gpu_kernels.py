@@ -322,6 +322,47 @@ def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
             assert (err < tol).all(), (D, W, skip, R, N, dtype, err)
 
 
+@pytest.mark.parametrize("tag", ["two_skips", "skip_first_and_late", "no_viewdirs_5ch", "no_viewdirs_4ch"])
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 8e-3), ("bf16", 6e-2)])
+def test_nerf_constructor_variants(ops, golden, tag, dtype, tol):
+    """The reference's whole NeRF signature (run_nerf_helpers.py:67-134) on every kernel: a `skips` list (several skips,
+    a skip right after layer 0), and use_viewdirs=False -- the output_linear head with 5 or 4 channels, no view
+    directions (run_network gets viewdirs=None, Trainer.py:792-800).  Expected raw comes from the reference's own
+    module.  fp32-grade paths at the golden gate (2e-5 of channel scale), 16-bit paths at operand-rounding size; the
+    mirrored module API (forward on the embedded input, Trainer.run_network) must agree with the direct call."""
+    from nerf_sampling_amd import synthetic
+    from nerf_sampling_amd.run_nerf_helpers import NeRF, get_embedder
+    from test_gpu_render import make_trainer
+
+    g = golden("nerf_variants")
+    kw = synthetic.NERF_VARIANTS[tag]
+    net = NeRF(D=kw["D"], W=kw["W"], input_ch=63, input_ch_views=kw.get("input_ch_views", 27), output_ch=kw.get("output_ch", 4),
+               skips=list(kw["skips"]), use_viewdirs=kw["use_viewdirs"])
+    net.load_state_dict(synthetic.make_nerf_params(**kw))
+    net = net.cuda()
+    exp = g[f"raw_{tag}"]
+    view = dev(g["viewdirs"]) if kw["use_viewdirs"] else None
+    raw = ops.nerf_forward(net.packed(dtype), dev(g["pts"]), view)
+    assert tuple(raw.shape) == exp.shape
+    scale = np.abs(exp).reshape(-1, exp.shape[-1]).max(0)
+    err = np.abs(raw.cpu().numpy() - exp) / scale
+    print(f"nerf variant {tag} [{dtype}]: max err / channel scale {err.max():.2e}")
+    assert err.max() < tol, (tag, dtype, float(err.max()))
+    if dtype == "f32":
+        ops.set_compute_dtype("f32")
+        e1, _ = get_embedder(10, 0, 3)
+        e2, _ = get_embedder(4, 0, 3)
+        tr = make_trainer()
+        via = tr.run_network(dev(g["pts"]), view, net, embed_fn=e1, embeddirs_fn=e2 if kw["use_viewdirs"] else None)
+        assert torch.equal(via, raw)
+        x = e1(dev(g["pts"]).reshape(-1, 3))
+        if kw["use_viewdirs"]:
+            x = torch.cat([x, e2(view[:, None].expand(48, 5, 3).reshape(-1, 3))], -1)
+        fwd = net(x)                                    # NeRF.forward on the embedded input, as the reference's module
+        assert fwd.shape == (240, exp.shape[-1])
+        assert np.abs(fwd.cpu().numpy().reshape(exp.shape) - exp).max() / scale.max() < 2e-5
+
+
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
 def test_nerf_forward_embedded_and_rays(ops, gpu_modules, golden, scene):
     g = golden("nerf_mlp")

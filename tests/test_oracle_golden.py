@@ -341,3 +341,18 @@ def test_rays_staticcam(golden):
     close(batch, g["ray_batch"], 0, 0)
     close(o.reshape(g["rays_o"].shape), g["rays_o"], 0, 0)
     close(d.reshape(g["rays_d"].shape), g["rays_d"], 0, 0)
+
+
+@pytest.mark.parametrize("tag", ["two_skips", "skip_first_and_late", "no_viewdirs_5ch", "no_viewdirs_4ch"])
+def test_nerf_variants(golden, tag):
+    """NeRF constructor variants (run_nerf_helpers.py:67-134): several skips, a skip right after layer 0, and the
+    use_viewdirs=False head (output_linear with 5 / 4 channels, fed the 63 point features only)."""
+    from nerf_sampling_amd import synthetic
+
+    g = golden("nerf_variants")
+    kw = synthetic.NERF_VARIANTS[tag]
+    p = synthetic.make_nerf_params(**kw)
+    view = T(g["viewdirs"]) if kw["use_viewdirs"] else None
+    raw = O.run_network(p, T(g["pts"]), view, skips=kw["skips"])
+    assert raw.shape == g[f"raw_{tag}"].shape
+    close(raw, g[f"raw_{tag}"], 1e-5, 1e-5)

@@ -391,6 +391,31 @@ def main():
                                                       K=K57, near=2.0, far=6.0, rays=None)
         save("staticcam", H=5, W=7, K=K57, c2w=c2w_a, c2w_staticcam=c2w_b, ray_batch=batch, rays_o=o, rays_d=d)
 
+        # ---- a7 NeRF constructor variants (run_nerf_helpers.py:67-134): several skips, skip after layer 0, and the
+        #      use_viewdirs=False head (output_linear, 4 or 5 channels; run_network is then called with viewdirs=None and
+        #      the network sees the 63 point features only, Trainer.py:792-800)
+        print("a7 nerf variants")
+        from nerf_sampling_amd import synthetic
+
+        g4 = torch.Generator().manual_seed(777)
+        pts_v = (torch.rand(48, 5, 3, generator=g4) * 2 - 1) * 2.5
+        view_v = torch.nn.functional.normalize(torch.randn(48, 3, generator=g4), dim=-1)
+        out = {"pts": pts_v, "viewdirs": view_v}
+        tr = make_trainer(ref)
+        embed_fn, _ = ref.helpers.get_embedder(10, 0, 3)
+        embeddirs_fn, _ = ref.helpers.get_embedder(4, 0, 3)
+        for tag, kw in synthetic.NERF_VARIANTS.items():
+            params = synthetic.make_nerf_params(**kw)
+            net = ref.helpers.NeRF(D=kw["D"], W=kw["W"], input_ch=63, input_ch_views=kw.get("input_ch_views", 27),
+                                   output_ch=kw.get("output_ch", 4), skips=list(kw["skips"]), use_viewdirs=kw["use_viewdirs"])
+            net.load_state_dict(params)
+            net.eval()
+            if kw["use_viewdirs"]:
+                out[f"raw_{tag}"] = tr.run_network(pts_v, view_v, net, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+            else:
+                out[f"raw_{tag}"] = tr.run_network(pts_v, None, net, embed_fn=embed_fn, embeddirs_fn=None)
+        save("nerf_variants", **out)
+
     if "--stats" in sys.argv:
         w = out  # noqa
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
