@@ -38,15 +38,21 @@ class _HostSink:
     `.cpu()` calls per chunk, nerf_utils.py:866-870) land in directly, asynchronously, on a side stream.
 
     The reference serialises the GPU on every chunk (a blocking D2H of ~42 MB at 32768 rays x 64 samples) and then
-    concatenates the chunks on the host (another pass over ~0.8 GB per 800x800 frame).  Here chunk i's copies overlap
-    chunk i+1's kernels and the "concatenation" is the buffer itself; the caller gets the same host tensors (same keys,
-    shapes, dtypes, values).  Buffers come from torch's caching pinned allocator, fresh per frame, so tensors returned
-    for one frame are never overwritten by the next (render_path keeps references across frames)."""
+    concatenates the chunks on the host (another pass over ~0.8 GB per 800x800 frame).  Here the "concatenation" is the
+    buffer itself and the copies of chunk i run UNDER THE NeRF-MLP KERNEL OF CHUNK i+1: put() only queues a copy, and
+    release(after=ev) starts the queued ones once `ev` -- the event the one-call renderer records right before its MLP
+    kernel -- has been reached.  (Measured on MI355X: ROCm moves these copies with shader blit kernels; started right
+    after a chunk they run beside the next chunk's small kernels -- DepthNet, placement -- and stretch them tenfold,
+    while the MFMA-bound MLP kernel that follows runs alone.  Under the MLP kernel they are nearly free.)  The caller
+    gets the same host tensors (same keys, shapes, dtypes, values).  Buffers come from torch's caching pinned allocator,
+    fresh per frame, so tensors returned for one frame are never overwritten by the next (render_path keeps references
+    across frames)."""
 
     def __init__(self, total_rows: int, device):
         self.total, self.device = int(total_rows), torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
         self.bufs, self.keep, self.row0 = {}, [], 0
+        self.pending, self.events = [], []
 
     def put(self, key: str, t: torch.Tensor) -> torch.Tensor:
         n = t.shape[0]
@@ -56,20 +62,41 @@ class _HostSink:
             buf = self.bufs[key] = torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device="cpu",
                                                pin_memory=True)
         dst = buf[self.row0 : self.row0 + n]
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(done)
-            dst.copy_(t, non_blocking=True)
-        self.keep.append(t)              # the device tensor stays alive until finish()
+        self.pending.append((dst, t))
         return dst
+
+    def new_event_pair(self):
+        pair = (ops.Event(), ops.Event())
+        self.events.append(pair)           # alive until the frame's copies are done
+        return pair
+
+    def release(self, after=None):
+        """Start every queued copy on the side stream: after the ops.Event ``after`` (already recorded on the compute
+        stream by work submitted earlier), or after everything submitted to the compute stream so far."""
+        if not self.pending:
+            return
+        if after is None:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.stream.wait_event(done)
+        else:
+            from ._lib import check, load
+
+            check(load().ns_stream_wait_event(ops.C.c_void_p(self.stream.cuda_stream), after.handle), "ns_stream_wait_event")
+        with torch.cuda.stream(self.stream):
+            for dst, t in self.pending:
+                dst.copy_(t, non_blocking=True)
+        self.keep.extend(t for _, t in self.pending)      # the device tensors stay alive until finish()
+        self.pending.clear()
 
     def advance(self, n_rows: int):
         self.row0 += int(n_rows)
 
     def finish(self):
+        self.release()
         self.stream.synchronize()
         self.keep.clear()
+        self.events.clear()
 
 
 _pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
@@ -101,6 +128,7 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
         if sink is not None:
             sink.advance(min(chunk, rays_flat.shape[0] - i))
     if sink is not None:
+        sink.release()                   # the last chunk's copies
         if defer:
             drain_host_copies()          # the previous frame: long finished by now
             _pending_sinks.append(sink)
@@ -369,6 +397,7 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
     # host copies (nerf_utils.py:820-822, 866-870): blocking `.cpu()` when called on its own; inside batchify_rays_test
     # they go asynchronously into the frame's pinned buffers (_HostSink)
     sink = kwargs.get("_host_sink")
+    released_early = False
     to_host = (lambda key, t: sink.put(key, t)) if sink is not None else (lambda key, t: t.cpu())
     if trainer.compare_nerf or trainer.use_nerf_max_pts or trainer.use_full_nerf:
         (_dens, fine_z, fine_pts, fine_rgb, fine_w, _al, fine_disp, fine_raw) = sample_as_in_NeRF(
@@ -391,10 +420,14 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
         # operator chain below (tests/test_gpu_render.py::test_fused_matches_operator_chain and the tagged-path test).
         dn = kwargs["depth_network"]
         net = network_fine if network_fine is not None else network_fn
+        ev = sink.new_event_pair() if sink is not None else None
         out = ops.render_rays_depthnet(dn.packed(), net.packed(), rays=(rays_o, rays_d, viewdirs),
                                        n_samples=trainer.n_depth_samples, mode=trainer.sampling_mode, std=trainer.distance,
                                        near=dn.near, far=dn.far, sphere_radius=float(dn.sphere_radius.reshape(-1)[0]),
-                                       white_bkgd=True, extras=True, device=rays_o.device)
+                                       white_bkgd=True, extras=True, device=rays_o.device, mlp_events=ev)
+        if sink is not None:
+            sink.release(after=ev[0])    # the PREVIOUS chunk's host copies start with this chunk's MLP kernel
+        released_early = True
         rgb_map, disp_map, weights, pts, z_vals = out["rgb"], out["disp"], out["weights"], out["pts"], out["z"]
     else:
         mean = kwargs["depth_network"](rays_o, rays_d)
@@ -410,4 +443,6 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
     ret["depth_net_disp_map"] = to_host("depth_net_disp_map", disp_map)
     ret["depth_net_z_vals"] = to_host("depth_net_z_vals", z_vals)
     ret["depth_net_pts"] = to_host("depth_net_pts", pts)
+    if sink is not None and not released_early:
+        sink.release()                   # branches without a single MLP kernel to hide behind: copy right away
     return ret
