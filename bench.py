@@ -367,7 +367,8 @@ class Timed:
         sync()
         t0 = time.perf_counter()
         for i in range(steps):
-            rgb, disp = self.renderer.render(poses[(warmup + i) % 40])
+            rgb, disp = self.renderer.render(poses[(warmup + i) % 40], wait=False)   # frame i's all-gather under frame i+1
+        self.renderer.finish()
         sync()
         elapsed = time.perf_counter() - t0
         return elapsed, rgb, disp

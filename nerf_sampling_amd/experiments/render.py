@@ -35,8 +35,10 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @click.option("-tmp", "--temporary", is_flag=True, default=False, help="Use temporary folder for experiment.",
               show_default=True)
 @click.option("-ip", "--i_print", default=1000, help="Frequency of log printing.", show_default=True)
-@click.option("--dtype", default="bf16", type=click.Choice(["bf16", "f16", "f32", "f16x3"]), show_default=True,
-              help="MFMA operand precision of the HIP kernels (not in the reference).")
+@click.option("--dtype", default="f16", type=click.Choice(["bf16", "f16", "f32", "f16x3"]), show_default=True,
+              help="MFMA operand precision of the HIP kernels (not in the reference).  This CLI's deliverable is a PSNR "
+                   "file, so the default is f16: on the fitted scene its per-image PSNR is within 0.007 dB of the fp32 "
+                   "arithmetic (bf16: 0.02 dB, 5 % faster; f16x3 / f32: identical to 1e-4 dB) -- tools/scene_psnr_sweep.py.")
 @click.option("--root", default=os.getcwd(), show_default=True,
               help="Directory holding dataset/ pretrained/ logs/ (the reference uses its package directory).")
 def main(**kw):

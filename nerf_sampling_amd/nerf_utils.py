@@ -89,6 +89,18 @@ class _HostSink:
         self.keep.extend(t for _, t in self.pending)      # the device tensors stay alive until finish()
         self.pending.clear()
 
+    def copy_whole(self, t: torch.Tensor) -> torch.Tensor:
+        """A pinned host copy of a whole device tensor, queued on the side stream behind everything submitted to the
+        compute stream so far; valid after finish()."""
+        dst = torch.empty(tuple(t.shape), dtype=t.dtype, device="cpu", pin_memory=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        self.stream.wait_event(done)
+        with torch.cuda.stream(self.stream):
+            dst.copy_(t, non_blocking=True)
+        self.keep.append(t)
+        return dst
+
     def advance(self, n_rows: int):
         self.row0 += int(n_rows)
 
@@ -100,6 +112,7 @@ class _HostSink:
 
 
 _pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
+_last_sink = None        # the sink of the most recent _batchify call (None: that call made blocking copies)
 
 
 def drain_host_copies():
@@ -116,6 +129,7 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
     reference's blocking `.cpu()` calls.  With ``_defer_host_sync=True`` (render_path's own loop) the tail of frame i's
     copies stays in flight under frame i+1's kernels: frame i-1 is drained here, frame i by drain_host_copies() or by
     the next frame."""
+    global _last_sink
     all_returned = {}
     sink = None
     defer = bool(kwargs.pop("_defer_host_sync", False))
@@ -127,6 +141,7 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
             all_returned.setdefault(key, []).append(returned[key])
         if sink is not None:
             sink.advance(min(chunk, rays_flat.shape[0] - i))
+    _last_sink = sink if defer else None
     if sink is not None:
         sink.release()                   # the last chunk's copies
         if defer:
@@ -220,17 +235,21 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
     rgbs, disps, all_pts, all_weights = [], [], [], []
     total_psnr, total_mse, psnr_info = 0, 0, None
     n_render_poses = render_poses.shape[0]
-    for i, c2w in enumerate(render_poses):
-        # the host copies of frame i stay in flight under frame i+1's kernels (SURVEY 8f-1 "asynchronous D2H of frames");
-        # they are drained before this loop reads them
-        rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], _defer_host_sync=True, **render_kwargs)
-        rgbs.append(rgb.cpu().numpy())
-        disps.append(disp.cpu().numpy())
+
+    def consume(i, rgb, disp, extras, sink):
+        """Everything the reference does with a finished frame (:303-355): host arrays, PSNR, PNG, psnr.txt, scene data."""
+        nonlocal total_psnr, total_mse, psnr_info
+        if sink is not None:
+            sink.finish()                                # this frame's host copies (rgb / disp included) are complete
+            rgbs.append(np.array(rgb.numpy()))           # pageable copies: the pinned buffers go back to the cache
+            disps.append(np.array(disp.numpy()))
+        else:
+            rgbs.append(rgb.cpu().numpy())
+            disps.append(disp.cpu().numpy())
         if gt_imgs is not None and render_factor == 0:
             psnr = -10.0 * np.log10(np.mean(np.square(rgbs[-1] - np.asarray(gt_imgs[i]))))
             psnr_info = f"{i:03d}.png, PSNR: {psnr}"
             if render_kwargs["trainer"].compare_nerf and extras.get("max_z_vals") is not None:
-                drain_host_copies()
                 mse = torch.nn.functional.mse_loss(extras["max_z_vals"], extras["depth_net_z_vals"])
                 total_mse += mse
                 psnr_info += f", MSE: {mse}"
@@ -252,10 +271,25 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
             if save_scene_data:
                 # pageable copies: the frame's pinned buffers go back to the allocator's cache instead of piling up
                 # (0.7 GB of page-locked memory per 800x800 frame otherwise)
-                drain_host_copies()
                 for dst, key in ((all_pts, "depth_net_pts"), (all_weights, "depth_net_weights")):
                     flat = torch.flatten(extras[key], end_dim=2)
                     dst.append(torch.empty(flat.shape, dtype=flat.dtype, device="cpu", pin_memory=False).copy_(flat))
+
+    # Software pipeline (SURVEY 8f-1 "asynchronous D2H of frames"): frame i+1 is submitted to the GPU BEFORE frame i is
+    # consumed on the host, so the PNG / PSNR work and the tail of frame i's host copies run under frame i+1's kernels.
+    # rgb / disp go to the host through the frame's copy stream too: a `.cpu()` on the compute stream would wait for
+    # frame i+1.  Output files, their order and their contents are the reference's.
+    prev = None
+    for i, c2w in enumerate(render_poses):
+        rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], _defer_host_sync=True, **render_kwargs)
+        sink = _last_sink if rgb.is_cuda else None
+        if sink is not None:
+            rgb, disp = sink.copy_whole(rgb), sink.copy_whole(disp)
+        if prev is not None:
+            consume(*prev)
+        prev = (i, rgb, disp, extras, sink)
+    if prev is not None:
+        consume(*prev)
     drain_host_copies()
     if save_scene_data and savedir is not None:
         torch.save({"all_pts": torch.cat(all_pts), "all_weights": torch.cat(all_weights)},

@@ -36,29 +36,56 @@ class FrameRenderer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.row0, self.row1, self.per = row_range(H, self.rank, self.world)
-        self.shard = torch.zeros((self.per * W, 4), dtype=torch.float32, device=self.device)
-        self.frame = (torch.empty((self.world * self.per * W, 4), dtype=torch.float32, device=self.device)
-                      if self.world > 1 else None)
+        # two shard / frame buffers: with wait=False the all-gather of frame i runs (on the collective's own stream)
+        # under the kernels of frame i+1, which write the other pair
+        self.shards = [torch.zeros((self.per * W, 4), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.frames = ([torch.empty((self.world * self.per * W, 4), dtype=torch.float32, device=self.device) for _ in range(2)]
+                       if self.world > 1 else [None, None])
+        self.cur, self.work = 0, [None, None]
+
+    @property
+    def shard(self) -> torch.Tensor:
+        return self.shards[self.cur]
 
     @property
     def rays_per_rank(self) -> int:
         return (self.row1 - self.row0) * self.W
 
-    def render(self, c2w) -> Tuple[torch.Tensor, torch.Tensor]:
-        """rgb [H,W,3], disp [H,W] of the whole frame, on every rank."""
+    def render(self, c2w, wait: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """rgb [H,W,3], disp [H,W] of the whole frame, on every rank.
+
+        wait=True (default): the tensors are ready for the caller's stream on return.  wait=False: the frame's
+        all-gather is left in flight (it overlaps the next frame's kernels); the returned tensors may be read after
+        finish(), or after the next-but-one render() -- the frame after next reuses their buffer."""
+        b = self.cur = self.cur ^ 1
+        if self.work[b] is not None:            # the gather that last used this buffer pair
+            self.work[b].wait()
+            self.work[b] = None
+        shard = self.shards[b]
         n = self.rays_per_rank
         if n > 0:
-            rgb, disp = self.render_rows(c2w, self.row0, self.row1, self.shard)
-            if rgb.data_ptr() != self.shard.data_ptr():          # a renderer that did not write the shard itself
-                self.shard[:n, :3] = rgb
-                self.shard[:n, 3] = disp
+            rgb, disp = self.render_rows(c2w, self.row0, self.row1, shard)
+            if rgb.data_ptr() != shard.data_ptr():               # a renderer that did not write the shard itself
+                shard[:n, :3] = rgb
+                shard[:n, 3] = disp
         if self.world == 1:
-            full = self.shard
+            full = shard
         else:
-            dist.all_gather_into_tensor(self.frame, self.shard, group=self.group)
-            full = self.frame
+            work = dist.all_gather_into_tensor(self.frames[b], shard, group=self.group, async_op=True)
+            if wait:
+                work.wait()
+            else:
+                self.work[b] = work
+            full = self.frames[b]
         full = full[: self.H * self.W]
         return full[:, :3].reshape(self.H, self.W, 3), full[:, 3].reshape(self.H, self.W)
+
+    def finish(self):
+        """Wait (on the caller's stream) for every all-gather render(wait=False) left in flight."""
+        for b in (0, 1):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
 
 
 def hip_row_renderer(depthnet, nerf, H: int, W: int, K, n_samples: int, mode: str, std: float, near: float = 2.0,

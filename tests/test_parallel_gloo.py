@@ -55,6 +55,16 @@ def _worker(rank, world, port, H, W, out_dir):
         rgb2, _ = fr.render(c2w)              # buffers are reused across frames
         assert torch.allclose(rgb, rgb2, rtol=0, atol=0, equal_nan=True)  # a corner ray misses the sphere: NaN, as the reference
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rgb=rgb.numpy(), disp=disp.numpy())
+        # pipelined mode: the all-gather of frame i stays in flight under frame i+1 (two shard / frame buffer pairs);
+        # after finish() the last two frames are intact and equal the synchronous renders
+        poses = [O.pose_spherical(a, -30.0, 4.0)[:3, :4] for a in (40.0, 75.0, 110.0)]
+        sync = [tuple(t.clone() for t in fr.render(p_)) for p_ in poses]
+        pipe = [fr.render(p_, wait=False) for p_ in poses]
+        fr.finish()
+        for k in (1, 2):
+            assert torch.equal(pipe[k][0], sync[k][0]) or torch.allclose(pipe[k][0], sync[k][0], equal_nan=True)
+            assert torch.allclose(pipe[k][1], sync[k][1], equal_nan=True)
+        assert pipe[0][0].data_ptr() == pipe[2][0].data_ptr()      # frame 2 reused frame 0's buffers
     finally:
         dist.destroy_process_group()
 
