@@ -326,8 +326,10 @@ def api_path_rate(coarse, fine, dn, dtype, H, W, K, poses, n_samples, device, fr
               use_viewdirs=True, white_bkgd=True, raw_noise_std=0.0, trainer=tr, lindisp=True, depth_network=dn,
               model_mode="test", near=2.0, far=6.0, ndc=False, _blocking_host_copies=blocking)
     with torch.no_grad():
-        for i in range(2 if blocking else 4):    # the pinned-buffer cache of the async sink takes three frames to fill
+        for i in range(2):
             rgb, disp, extras = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], **kw)
+        if not blocking:     # torch's pinned-memory cache takes a few frames of the same loop to reach its steady size
+            nerf_utils.render_path(poses[:4], [H, W, float(K[0][0])], K, tr.chunk, kw, step=0)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
         # the loop experiments/render.py runs: render_path = render_test per pose + rgb / disp to numpy (no PNGs here)

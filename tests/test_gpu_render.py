@@ -336,19 +336,15 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     assert torch.equal(lean["rgb"], ref["rgb"]) and torch.equal(lean["disp"], ref["disp"])
 
 
-# Measured on MI355X (tools/frame16_diag.py, profiles/r02_frame16_diag.log): rms error of the HIP sigma against the
-# oracle's at the same points, as a fraction of max |sigma| of the band.  bench.py uses the same constants for its mask.
-SIGMA_NOISE_FRAC = {"bf16": 1.55e-2, "f16": 2.4e-3}
-
-
-def conditioning_mask(raw_ref, z_ref, d, rgb_ref, sigma_eps, tol=1e-2):
-    """Rays whose ORACLE colour moves by more than `tol` when every sigma moves by +-sigma_eps: the reference composites
-    the last sample with dist = 1e10 (sampling_trainer.py:176-180), so alpha_last = step(sigma_last) and a ray's colour
-    is discontinuous in sigma_last wherever transmittance is left (the same mask as test_frame_config1_fp32_gate)."""
+def step_rule_mask(raw_ref, z_ref, d, rgb_ref, sigma_last_eps, tol=1e-2):
+    """Rays whose ORACLE colour moves by more than `tol` when sigma of the LAST sample alone moves by +-sigma_last_eps: the
+    reference composites the last sample with dist = 1e10 (sampling_trainer.py:176-180), so alpha_last = step(sigma_last)
+    and a ray's colour is discontinuous in sigma_last wherever transmittance is left.  Only that one value is perturbed:
+    the mask isolates the step rule and says nothing about a ray that is merely semi-transparent."""
     ill = torch.zeros(raw_ref.shape[0], dtype=torch.bool)
     for sgn in (-1.0, 1.0):
         pert = raw_ref.clone()
-        pert[..., 3] += sgn * sigma_eps
+        pert[:, -1, 3] += sgn * sigma_last_eps
         ill |= (O.raw2outputs(pert, z_ref, d, 0.0, True)[0] - rgb_ref).abs().max(-1).values > tol
     return ill
 
@@ -379,17 +375,19 @@ def oracle_band():
                 rgb=rgb)
 
 
-#                                  z rms   sigma/max  ill frac  PSNR well  PSNR with oracle sigma_last   (gates <= ~3x measured)
-@pytest.mark.parametrize("dtype,g_z,g_sig,g_ill,g_psnr,g_fix", [("bf16", 1.0e-2, 4.0e-2, 0.15, 58.0, 47.0),
-                                                               ("f16", 1.4e-3, 7.0e-3, 0.04, 68.0, 54.0)])
-def test_frame16_vs_oracle(gpu_modules, oracle_band, dtype, g_z, g_sig, g_ill, g_psnr, g_fix):
-    """The headline 16-bit path against the ORACLE at image level, on the configs[1] shape.
+#                                  z rms   sigma/max  all-ray PSNR  step-rule frac  PSNR with oracle sigma_last   (gates <= ~3x measured)
+@pytest.mark.parametrize("dtype,g_z,g_sig,g_all,g_step,g_fix", [("bf16", 1.0e-2, 4.0e-2, 21.0, 0.10, 47.0),
+                                                                ("f16", 1.4e-3, 7.0e-3, 28.0, 0.03, 54.0)])
+def test_frame16_vs_oracle(gpu_modules, oracle_band, dtype, g_z, g_sig, g_all, g_step, g_fix):
+    """The 16-bit paths against the ORACLE at image level on the configs[1] shape, on the STRESS scene (lego_synth: seeded
+    random weights whose density crosses zero at the last sample of every fifth ray; the realistic, fitted scene is
+    tests/test_scene_psnr.py).  Gated: the stage errors at identical inputs; the all-ray PSNR; and the two figures that
+    isolate the reference's last-sample step rule (alpha_last = step(sigma_last)) with NO per-dtype constant -- the
+    fraction of rays whose oracle colour flips when sigma_last alone moves by 3x the sigma_last error measured in this
+    very run, and the PSNR of the HIP raw composited with only sigma_last taken from the oracle.
 
-    Measured (MI355X, round 2): bf16 / f16  z rms 3.3e-3 / 4.6e-4;  sigma noise 1.54e-2 / 2.4e-3 of max |sigma|;
-    PSNR(build || oracle) over ALL rays 24.2 / 31.3 dB, over the well-conditioned rays 68.7 / 79.7 dB with 11.5 % / 2.5 %
-    of rays ill-conditioned at 3x the measured sigma noise; every ray that differs by > 1e-2 is inside the mask; and
-    compositing the HIP raw with the ORACLE's sigma_last alone restores 52.5 / 60.1 dB over all rays -- i.e. the
-    all-ray PSNR is the last-sample step rule (alpha_last = step(sigma_last)), not an accuracy problem of the kernels."""
+    Measured (MI355X): bf16 / f16  z rms 3.3e-3 / 4.6e-4;  sigma noise 1.54e-2 / 2.4e-3 of max |sigma|; all-ray PSNR
+    24.2 / 31.3 dB; with the oracle's sigma_last 52.5 / 60.1 dB."""
     from nerf_sampling_amd import ops
 
     b = oracle_band
@@ -407,32 +405,30 @@ def test_frame16_vs_oracle(gpu_modules, oracle_band, dtype, g_z, g_sig, g_ill, g
         rgb_o_given_z = O.raw2outputs(raw_o, zz.cpu(), b["d"], 0.0, True)[0]
     sig_max = float(b["raw"][..., 3].abs().max())
     sig_frac = float((raw[..., 3] - raw_o[..., 3]).pow(2).mean().sqrt()) / sig_max
+    last_rms = float((raw[:, -1, 3] - raw_o[:, -1, 3]).pow(2).mean().sqrt())
     logit_rms = float((raw[..., :3] - raw_o[..., :3]).pow(2).mean().sqrt())
     # the frame itself: the one-call fused path on camera rays (what bench.py times)
     out = ops.render_rays_depthnet(dn, nf, camera=(b["H"], b["W"], b["K"], b["c2w"], b["r0"], b["r0"] + b["rows"]),
                                    n_samples=64, mode="uniform", std=0.1)
     rgb = out["rgb"].cpu()
     err = (rgb - b["rgb"]).abs().max(-1).values
-    ill = conditioning_mask(b["raw"], b["z"], b["d"], b["rgb"], 3.0 * SIGMA_NOISE_FRAC[dtype] * sig_max)
-    well = ~ill
-    psnr_all, psnr_well = _psnr(rgb, b["rgb"]), _psnr(rgb[well], b["rgb"][well])
-    big = err > 1e-2
+    ill = step_rule_mask(b["raw"], b["z"], b["d"], b["rgb"], 3.0 * last_rms)
+    psnr_all = _psnr(rgb, b["rgb"])
     # the last-sample rule in isolation: HIP raw, oracle's sigma_last
     raw_fix = raw.clone()
     raw_fix[:, -1, 3] = raw_o[:, -1, 3]
     with torch.no_grad():
         rgb_fix = O.raw2outputs(raw_fix, zz.cpu(), b["d"], 0.0, True)[0]
     psnr_fix = _psnr(rgb_fix, rgb_o_given_z)
-    print(f"{dtype}: z rms {z_rms:.2e}; sigma noise {sig_frac:.2e} of max|sigma| ({sig_max:.1f}); rgb-logit rms {logit_rms:.2e}; "
-          f"PSNR all {psnr_all:.2f} dB, well-conditioned {psnr_well:.2f} dB (max err {float(err[well].max()):.2e}); "
-          f"ill {float(ill.float().mean()):.4f}; err>1e-2: {float(big.float().mean()):.4f} of rays, "
-          f"{float((big & well).float().mean()):.5f} outside the mask; with oracle sigma_last {psnr_fix:.2f} dB")
+    print(f"{dtype}: z rms {z_rms:.2e}; sigma noise {sig_frac:.2e} of max|sigma| ({sig_max:.1f}), at the last sample rms "
+          f"{last_rms:.3g}; rgb-logit rms {logit_rms:.2e}; PSNR all rays {psnr_all:.2f} dB; step-rule rays "
+          f"{float(ill.float().mean()):.4f}; err>1e-2: {float((err > 1e-2).float().mean()):.4f} of rays; with oracle "
+          f"sigma_last {psnr_fix:.2f} dB")
     assert z_rms < g_z
-    assert sig_frac < g_sig and abs(sig_frac / SIGMA_NOISE_FRAC[dtype] - 1.0) < 0.3     # the mask's noise level is the measured one
-    assert float(ill.float().mean()) < g_ill
-    assert psnr_well > g_psnr and float(err[well].max()) < 2e-2
-    assert float((big & well).float().mean()) < 2e-4          # every visibly different ray is an ill-conditioned one
-    assert psnr_fix > g_fix                                    # ... and the step rule at the last sample is what differs
+    assert sig_frac < g_sig
+    assert psnr_all > g_all
+    assert float(ill.float().mean()) < g_step
+    assert psnr_fix > g_fix                                    # the step rule at the last sample is what differs
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -567,19 +563,19 @@ def test_async_host_copies_equal_blocking_copies(gpu_modules, flags):
 
 
 def test_config5_band_vs_oracle_f16():
-    """BASELINE configs[4] shape (1600x1600, DepthNet + 192 samples/ray, fp16 MFMA): a 6-row band against the oracle with
-    the same conditioning mask as test_frame16_vs_oracle (3x the measured f16 sigma noise)."""
+    """BASELINE configs[4] shape (1600x1600, DepthNet + 192 samples/ray, fp16 MFMA) on the FITTED scene: a 6-row band
+    against the oracle over ALL rays, and the scene PSNR against the analytic ground truth on both sides."""
     from conftest import _make_modules
-    from nerf_sampling_amd import ops
+    from nerf_sampling_amd import analytic_scene, ops
 
     torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
-    m = _make_modules("lego_synth")
+    m = _make_modules("shapes_fit")
     p = m["params"]
     H = W = 1600
     N = 192
     _, K = O.blender_intrinsics(H, W)
-    c2w = O.pose_spherical(-135.0, -30.0, 4.0)[:3, :4]
-    r0, rows = 797, 6
+    c2w = O.render_poses(40)[7][:3, :4]
+    r0, rows = 880, 6
     batch, o, d, _ = O.ray_batch_from_camera(H, W, K, c2w, 2.0, 6.0)
     sl = slice(r0 * W, (r0 + rows) * W)
     batch, o, d = batch[sl], o[sl], d[sl]
@@ -591,16 +587,14 @@ def test_config5_band_vs_oracle_f16():
     out = ops.render_rays_depthnet(m["depth"].packed("f16"), m["fine"].packed("f16"), camera=(H, W, K, c2w, r0, r0 + rows),
                                    n_samples=N, mode="uniform", std=0.1)
     rgb = out["rgb"].cpu()
+    gt = analytic_scene.frame(H, W, K, c2w, r0, r0 + rows)[0].reshape(-1, 3)
     err = (rgb - rgb_ref).abs().max(-1).values
-    ill = conditioning_mask(raw, z, d, rgb_ref, 3.0 * SIGMA_NOISE_FRAC["f16"] * float(raw[..., 3].abs().max()))
-    well = ~ill
-    print(f"config5 f16 band: PSNR all {_psnr(rgb, rgb_ref):.2f} dB, well-conditioned {_psnr(rgb[well], rgb_ref[well]):.2f} dB "
-          f"(max err {float(err[well].max()):.2e}); ill {float(ill.float().mean()):.4f}; "
-          f"err>1e-2 outside the mask {float(((err > 1e-2) & well).float().mean()):.5f}")
-    # measured (round 2): well-conditioned 81.5 dB (max err 5.5e-4), 3.6 % ill-conditioned, nothing outside the mask
-    assert float(ill.float().mean()) < 0.08
-    assert _psnr(rgb[well], rgb_ref[well]) > 71.0 and float(err[well].max()) < 2e-3
-    assert float(((err > 1e-2) & well).float().mean()) < 5e-4
+    p_ref, p_build = _psnr(rgb_ref, gt), _psnr(rgb, gt)
+    print(f"config5 f16 band (fitted scene): PSNR build vs oracle, all rays {_psnr(rgb, rgb_ref):.2f} dB; median |err| "
+          f"{float(err.median()):.2e}; err>1e-2 {float((err > 1e-2).float().mean()):.5f}; scene PSNR oracle {p_ref:.4f} dB, build "
+          f"{p_build:.4f} dB, delta {p_build - p_ref:+.4f} dB")
+    assert _psnr(rgb, rgb_ref) > 32.0 and float(err.median()) < 5e-4
+    assert abs(p_build - p_ref) <= 0.05
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16"])

@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/nerf_sampling_amd/csrc
+src=${NS_VARIANT_SRC:-$root/nerf_sampling_amd/csrc}   # NS_VARIANT_SRC: build the kernels of another checkout (A/B against an older commit)
 bld=/tmp/ns_variant_$name
 mkdir -p $bld
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off $*"

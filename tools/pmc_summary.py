@@ -30,16 +30,17 @@ for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_trace.csv"), recursiv
         tail = [x[1] for x in v[-5:]]       # the timed launches (the last 5 of 2 warm-up + 5)
         print(f"trace  {k:24s} last-5 mean {sum(tail) / len(tail) / 1e6:9.4f} ms")
         out.setdefault(k, {})["trace_last5_ms"] = sum(tail) / len(tail) / 1e6
-for p in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_inst"):
+for p in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_inst", "pmc_sq_f16"):
     for f in glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
+            key = k + ("[f16]" if p.endswith("_f16") else "")
             for c, v in cs.items():
                 m = sum(v) / len(v)
-                print(f"{p:9s} {k:24s} {c:32s} {m:.6g}  (n={len(v)})")
-                out.setdefault(k, {})[c] = m
+                print(f"{p:9s} {key:24s} {c:32s} {m:.6g}  (n={len(v)})")
+                out.setdefault(key, {})[c] = m
 for k, c in out.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
         print(f"derived {k}: MFMA-pipe busy {c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / (c['GRBM_GUI_ACTIVE'] / 8):.4f} of cycles")
