@@ -35,6 +35,15 @@ with torch.no_grad():
     # the loop experiments/render.py runs: render_path keeps frame i's host copies in flight under frame i+1's kernels
     kw["network_query_fn"] = nerf_utils.standard_query_fn(lambda i, v, f: q(i, v, f))
     n = int(os.environ.get("NS_API_FRAMES", "8"))
+    # host side of one frame: time until render_test has SUBMITTED everything (no synchronisation)
+    torch.cuda.synchronize()
+    sub = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        rgb, disp, ex = nerf_utils.render_test(H, W, K, chunk=tr.chunk, c2w=poses[i], _defer_host_sync=True, **kw)
+        sub.append(1e3 * (time.perf_counter() - t0))
+    nerf_utils.drain_host_copies(); torch.cuda.synchronize()
+    print("host time to submit a frame (ms; includes waiting for the previous frame's copies):", " ".join(f"{t:5.1f}" for t in sub))
     for rep in range(3):      # the first pass still grows torch's pinned-memory cache (one more frame's buffers in flight)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         nerf_utils.render_path(poses[3 : 3 + n], [H, W, float(K[0][0])], K, tr.chunk, kw, step=0)
