@@ -286,6 +286,18 @@ int ns_adam_step_dev(float* p_dev, const float* g_dev, float* m_dev, float* v_de
                      const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev,
                      void* stream);
 int ns_add_i32(int* x_dev, int delta, void* stream);
+/* ns_adam_step_dev for EVERY parameter tensor of the optimiser in one launch: table_dev = n_tensors rows {p, g, m, v, n}
+ * in device memory, max_n = the largest n (82 launches per DepthNet step become one)                                  */
+typedef struct ns_adam_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} ns_adam_tensor;
+int ns_adam_step_multi_dev(const ns_adam_tensor* table_dev, int n_tensors, int64_t max_n, float lr,
+                           const float* lr_dev, float beta1, float beta2, float eps, const int* step_dev,
+                           void* stream);
 
 /* ---- timing helpers (hipEvent_t as void*) used by bench.py for the live roofline figure --------- */
 int ns_event_create(void** ev);

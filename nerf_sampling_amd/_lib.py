@@ -101,6 +101,7 @@ SIGNATURES = {
     "ns_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _i, _p]),
     "ns_adam_step_dev": (_i, [_p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _p, _p]),
     "ns_add_i32": (_i, [_p, _i, _p]),
+    "ns_adam_step_multi_dev": (_i, [_p, _i, _i64, _f, _p, _f, _f, _f, _p, _p]),
     "ns_event_create": (_i, [C.POINTER(_p)]),
     "ns_event_destroy": (None, [_p]),
     "ns_event_record": (_i, [_p, _p]),

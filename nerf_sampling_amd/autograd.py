@@ -319,7 +319,31 @@ class HipAdam(torch.optim.Adam):
                 if not capturing:
                     self.sync_device_lr()
                     self._host_steps += 1
-                check(lib.ns_add_i32(_ptr(self._dev_step), 1, _stream(self._dev_step.device)), "ns_add_i32")
+                dev = self._dev_step.device
+                check(lib.ns_add_i32(_ptr(self._dev_step), 1, _stream(dev)), "ns_add_i32")
+                # one launch for all parameter tensors: {p, g, m, v, n} rows, staged through a pinned host tensor (an
+                # asynchronous copy from pinned memory is also what a hipGraph capture can record; the rows stay valid
+                # across replays because the captured backward writes its gradients to the same addresses every time)
+                rows, keep, max_n = [], [], 0
+                for p in group["params"]:
+                    if p.grad is None:
+                        continue
+                    st = self._init_state(p)
+                    g = p.grad.contiguous()
+                    keep.append(g)
+                    rows += [p.data.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
+                    max_n = max(max_n, p.numel())
+                if rows:
+                    host = torch.tensor(rows, dtype=torch.int64, device="cpu").pin_memory()
+                    table = host.to(dev, non_blocking=True)
+                    if capturing:     # a replayed graph re-reads the pinned rows on every replay: they live as long as the optimiser
+                        self._captured_tables = getattr(self, "_captured_tables", []) + [(host, table, keep)]
+                    else:             # eager: alive until the asynchronous copy and the launch have certainly run
+                        self._adam_tables = getattr(self, "_adam_tables", [])[-7:] + [(host, table, keep)]
+                    check(lib.ns_adam_step_multi_dev(_ptr(table), len(rows) // 5, max_n, float(group["lr"]), _ptr(self._dev_lr),
+                                                     float(b1), float(b2), float(group["eps"]), _ptr(self._dev_step), _stream(dev)),
+                          "ns_adam_step_multi_dev")
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue

@@ -169,6 +169,23 @@ adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
 
 __global__ void add_i32_kernel(int* __restrict__ x, int delta) { *x += delta; }
 
+// every parameter tensor of the optimiser in ONE launch: blockIdx.y = tensor, table row = {p, g, m, v, n}
+__global__ void __launch_bounds__(256)
+adam_multi_dev_kernel(const ns_adam_tensor* __restrict__ table, float lr, const float* __restrict__ lr_dev, float b1,
+                      float b2, float eps, const int* __restrict__ step_dev) {
+  const ns_adam_tensor t = table[blockIdx.y];
+  const float step = static_cast<float>(*step_dev);
+  const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+  if (lr_dev) lr = *lr_dev;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < t.n; i += (int64_t)gridDim.x * 256) {
+    const float gi = t.g[i];
+    const float mi = t.m[i] = b1 * t.m[i] + (1.f - b1) * gi;
+    const float vi = t.v[i] = b2 * t.v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    t.p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,6 +276,19 @@ int ns_adam_step_dev(float* p_dev, const float* g_dev, float* m_dev, float* v_de
   NS_REQUIRE(p_dev && g_dev && m_dev && v_dev && step_dev, "null pointer");
   adam_dev_kernel<<<ns::ew_grid(n, 256), 256, 0, ns::as_stream(stream)>>>(p_dev, g_dev, m_dev, v_dev, n, lr, lr_dev, beta1,
                                                                          beta2, eps, step_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_adam_step_multi_dev(const ns_adam_tensor* table_dev, int n_tensors, int64_t max_n, float lr, const float* lr_dev,
+                           float beta1, float beta2, float eps, const int* step_dev, void* stream) {
+  NS_REQUIRE(n_tensors >= 0 && max_n >= 0, "bad argument");
+  if (n_tensors == 0 || max_n == 0) return NS_OK;
+  NS_REQUIRE(table_dev && step_dev && n_tensors <= 65535, "null pointer / too many tensors");
+  int64_t bx = ns::cdiv(max_n, 256);
+  if (bx > 256) bx = 256;                      // grid-stride over the larger tensors
+  adam_multi_dev_kernel<<<dim3(static_cast<unsigned>(bx), static_cast<unsigned>(n_tensors)), 256, 0, ns::as_stream(stream)>>>(
+      table_dev, lr, lr_dev, beta1, beta2, eps, step_dev);
   NS_LAUNCH_CHECK();
   return NS_OK;
 }

@@ -48,19 +48,35 @@ class _HostSink:
     fresh per frame, so tensors returned for one frame are never overwritten by the next (render_path keeps references
     across frames)."""
 
-    def __init__(self, total_rows: int, device):
-        self.total, self.device = int(total_rows), torch.device(device)
+    def __init__(self, total_rows: int, device, pooled: bool = False):
+        self.total, self.device, self.pooled = int(total_rows), torch.device(device), pooled
         self.stream = torch.cuda.Stream(self.device)
         self.bufs, self.keep, self.row0 = {}, [], 0
-        self.pending, self.events = [], []
+        self.pending, self.events, self.whole = [], [], []
+
+    def _pinned(self, key, shape, dtype):
+        """A pinned host buffer: fresh from torch's caching pinned allocator, or -- pooled=True, render_path's own loop,
+        which knows when a frame's host tensors are dead -- one that recycle() handed back (torch's allocator took tens of
+        frames to settle on 0.8 GB-per-frame requests: 35-55 ms/frame instead of 31)."""
+        # device="cpu" explicitly: the experiment scripts switch torch's DEFAULT device to cuda (utils.py:143-149)
+        free = _sink_pool.get((key, tuple(shape), dtype)) if self.pooled else None
+        return free.pop() if free else torch.empty(tuple(shape), dtype=dtype, device="cpu", pin_memory=True)
+
+    def recycle(self):
+        """Hand this (finished, consumed) frame's pinned buffers to the pool.  Only render_path calls this: the tensors it
+        got from render_test for this frame must not be read afterwards."""
+        self.finish()
+        for key, buf in self.bufs.items():
+            _sink_pool.setdefault((key, tuple(buf.shape), buf.dtype), []).append(buf)
+        for buf in self.whole:
+            _sink_pool.setdefault(("__whole__", tuple(buf.shape), buf.dtype), []).append(buf)
+        self.bufs, self.whole = {}, []
 
     def put(self, key: str, t: torch.Tensor) -> torch.Tensor:
         n = t.shape[0]
         buf = self.bufs.get(key)
         if buf is None:
-            # device="cpu" explicitly: the experiment scripts switch torch's DEFAULT device to cuda (utils.py:143-149)
-            buf = self.bufs[key] = torch.empty((self.total,) + tuple(t.shape[1:]), dtype=t.dtype, device="cpu",
-                                               pin_memory=True)
+            buf = self.bufs[key] = self._pinned(key, (self.total,) + tuple(t.shape[1:]), t.dtype)
         dst = buf[self.row0 : self.row0 + n]
         self.pending.append((dst, t))
         return dst
@@ -92,7 +108,8 @@ class _HostSink:
     def copy_whole(self, t: torch.Tensor) -> torch.Tensor:
         """A pinned host copy of a whole device tensor, queued on the side stream behind everything submitted to the
         compute stream so far; valid after finish()."""
-        dst = torch.empty(tuple(t.shape), dtype=t.dtype, device="cpu", pin_memory=True)
+        dst = self._pinned("__whole__", t.shape, t.dtype)
+        self.whole.append(dst)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         self.stream.wait_event(done)
@@ -111,6 +128,7 @@ class _HostSink:
         self.events.clear()
 
 
+_sink_pool = {}          # (key, shape, dtype) -> pinned buffers recycled by render_path (emptied when it returns)
 _pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
 _last_sink = None        # the sink of the most recent _batchify call (None: that call made blocking copies)
 
@@ -134,7 +152,7 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
     sink = None
     defer = bool(kwargs.pop("_defer_host_sync", False))
     if render_fn is render_rays_test and rays_flat.is_cuda and not kwargs.get("_blocking_host_copies", False):
-        sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device)
+        sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device, pooled=defer)
     for i in range(0, rays_flat.shape[0], chunk):
         returned = render_fn(rays_flat[i : i + chunk], **kwargs)
         for key in returned:
@@ -274,6 +292,8 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
                 for dst, key in ((all_pts, "depth_net_pts"), (all_weights, "depth_net_weights")):
                     flat = torch.flatten(extras[key], end_dim=2)
                     dst.append(torch.empty(flat.shape, dtype=flat.dtype, device="cpu", pin_memory=False).copy_(flat))
+        if sink is not None:
+            sink.recycle()                               # nothing of this frame's host tensors is read from here on
 
     # Software pipeline (SURVEY 8f-1 "asynchronous D2H of frames"): frame i+1 is submitted to the GPU BEFORE frame i is
     # consumed on the host, so the PNG / PSNR work and the tail of frame i's host copies run under frame i+1's kernels.
@@ -290,6 +310,7 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
         prev = (i, rgb, disp, extras, sink)
     if prev is not None:
         consume(*prev)
+    _sink_pool.clear()                                   # the pinned buffers go back to torch's cache
     drain_host_copies()
     if save_scene_data and savedir is not None:
         torch.save({"all_pts": torch.cat(all_pts), "all_weights": torch.cat(all_weights)},
