@@ -263,6 +263,7 @@ class HipAdam(torch.optim.Adam):
 
     _dev_step: Optional[Tensor] = None
     _dev_lr: Optional[Tensor] = None
+    _table_event = None
     _host_steps = 0          # steps taken through the device counter (eager calls and graph replays alike)
 
     def _init_state(self, p):
@@ -288,6 +289,11 @@ class HipAdam(torch.optim.Adam):
         self._lr_seen = float(self.param_groups[0]["lr"])
         for p in params:
             self._init_state(p)
+        # two row tables, [0] for eager steps and [1] for a captured step (a replayed graph re-reads its pinned rows on
+        # every replay, so eager steps taken after a capture must not touch them)
+        self._table_host = [torch.empty((5 * len(params),), dtype=torch.int64, device="cpu").pin_memory() for _ in range(2)]
+        self._table_dev = [torch.empty((5 * len(params),), dtype=torch.int64, device=dev) for _ in range(2)]
+        self._table_event = None
 
     def note_replayed_step(self):
         """A captured graph containing step() was replayed once."""
@@ -321,9 +327,10 @@ class HipAdam(torch.optim.Adam):
                     self._host_steps += 1
                 dev = self._dev_step.device
                 check(lib.ns_add_i32(_ptr(self._dev_step), 1, _stream(dev)), "ns_add_i32")
-                # one launch for all parameter tensors: {p, g, m, v, n} rows, staged through a pinned host tensor (an
-                # asynchronous copy from pinned memory is also what a hipGraph capture can record; the rows stay valid
-                # across replays because the captured backward writes its gradients to the same addresses every time)
+                # one launch for all parameter tensors: {p, g, m, v, n} rows, staged through a pinned host tensor that was
+                # allocated BEFORE any capture (use_device_step): an asynchronous copy from pinned memory is something a
+                # hipGraph capture records (an allocation is not), and the rows stay valid across replays because the
+                # captured backward writes its gradients to the same addresses every time
                 rows, keep, max_n = [], [], 0
                 for p in group["params"]:
                     if p.grad is None:
@@ -334,15 +341,18 @@ class HipAdam(torch.optim.Adam):
                     rows += [p.data.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
                     max_n = max(max_n, p.numel())
                 if rows:
-                    host = torch.tensor(rows, dtype=torch.int64, device="cpu").pin_memory()
-                    table = host.to(dev, non_blocking=True)
-                    if capturing:     # a replayed graph re-reads the pinned rows on every replay: they live as long as the optimiser
-                        self._captured_tables = getattr(self, "_captured_tables", []) + [(host, table, keep)]
-                    else:             # eager: alive until the asynchronous copy and the launch have certainly run
-                        self._adam_tables = getattr(self, "_adam_tables", [])[-7:] + [(host, table, keep)]
-                    check(lib.ns_adam_step_multi_dev(_ptr(table), len(rows) // 5, max_n, float(group["lr"]), _ptr(self._dev_lr),
-                                                     float(b1), float(b2), float(group["eps"]), _ptr(self._dev_step), _stream(dev)),
-                          "ns_adam_step_multi_dev")
+                    if not capturing and self._table_event is not None:
+                        self._table_event.synchronize()          # the previous step's copy of the rows has been taken
+                    n_rows, k = len(rows) // 5, int(capturing)
+                    self._table_host[k][: len(rows)].copy_(torch.tensor(rows, dtype=torch.int64, device="cpu"))
+                    self._table_dev[k][: len(rows)].copy_(self._table_host[k][: len(rows)], non_blocking=True)
+                    if not capturing:
+                        self._table_event = torch.cuda.Event()
+                        self._table_event.record(torch.cuda.current_stream(dev))
+                    self._table_keep = keep                      # gradient tensors the launch reads
+                    check(lib.ns_adam_step_multi_dev(_ptr(self._table_dev[k]), n_rows, max_n, float(group["lr"]),
+                                                     _ptr(self._dev_lr), float(b1), float(b2), float(group["eps"]),
+                                                     _ptr(self._dev_step), _stream(dev)), "ns_adam_step_multi_dev")
                 continue
             for p in group["params"]:
                 if p.grad is None:
