@@ -132,10 +132,10 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     uint32_t bad = 0;
     auto finite = [](float v) { return __builtin_fabsf(v) < __builtin_inff(); };
     asm volatile("" ::: "memory");   // the staged inputs landed several slab steps ago (in-order vmcnt)
-    static_for<T>([&](auto t_) {
-      constexpr int t = decltype(t_)::value;
-      Block ve[1];    // embedded view direction (27 -> 32)
-      if constexpr (EMBEDDED) {
+    if constexpr (EMBEDDED) {
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        Block ve[1];    // embedded view direction (27 -> 32)
         bool valid;
         const float* row = a.x90 + sample_of(grp, t, n, valid) * a.x_stride;
         gather3_16<M, 10, 2>(xe[t], row, g);
@@ -145,29 +145,72 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
           ok = ok && finite(row[63]) && finite(row[64]) && finite(row[65]);
         }
         if (!ok) bad |= 1u << t;
-      } else {
-        float p[3], v[3];
+        stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]);
+        if (a.use_viewdirs) stash_put(t, 2, ve[0]);
+      });
+    } else {
+      // All staged values of the wave's four tiles come out of LDS in ONE burst (40 reads, one wait) before anything is
+      // embedded or stashed: read tile by tile, each read sat right in front of its first use (an exposed LDS latency per
+      // value, ~3 % of the kernel: nothing else runs on this SIMD while the lone wave waits).
+      float P[T][3], V[T][3];          // (compile-time indices only: a runtime index would park the arrays in scratch)
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
         if (a.pts) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) p[c] = staged(t, c);
+          static_for<3>([&](auto c_) { P[t][decltype(c_)::value] = staged(t, decltype(c_)::value); });
         } else {
           const float zz = staged(t, 6);
-#pragma unroll
-          for (int c = 0; c < 3; ++c) p[c] = staged(t, c) + staged(t, 3 + c) * zz;
+          static_for<3>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            P[t][c] = staged(t, c) + staged(t, 3 + c) * zz;
+          });
         }
-        bool ok = finite(p[0]) && finite(p[1]) && finite(p[2]);
-        embed3_16<M, false, 10, 2>(xe[t], p[0], p[1], p[2], g);
+        static_for<3>([&](auto c_) {
+          constexpr int c = decltype(c_)::value;
+          V[t][c] = a.use_viewdirs ? staged(t, 7 + c) : 0.0f;
+        });
+      });
+      asm volatile("" ::: "memory");   // ... and only then the stash writes below (the compiler cannot tell the two LDS regions apart)
+      // One view direction for the whole wave (its 64 consecutive samples lie on one ray whenever N is a multiple of 64,
+      // the headline case): embed it once instead of once per tile.  Compared by VALUE, wave-uniformly; a NaN compares
+      // unequal and takes the per-tile path.
+      bool same_view = a.use_viewdirs != 0;
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        if constexpr (t > 0) same_view = same_view && V[t][0] == V[0][0] && V[t][1] == V[0][1] && V[t][2] == V[0][2];
+      });
+      same_view = __builtin_amdgcn_ballot_w64(same_view) == ~0ull;
+      Block ve0[1];
+#ifdef NS_EXP_NOEMBED      // timing ablation: no positional encoding (results are wrong)
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        float x8[8];
+        static_for<8>([&](auto e_) { x8[decltype(e_)::value] = P[t][decltype(e_)::value % 3] + V[t][decltype(e_)::value % 3]; });
+        xe[t][0] = M::from_f32(x8); xe[t][1] = xe[t][0];
+        stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, xe[t][0]);
+      });
+      if (false)
+#endif
+      if (same_view) embed3_16<M, false, 4, 1>(ve0, V[0][0], V[0][1], V[0][2], g);
+#ifndef NS_EXP_NOEMBED
+      static_for<T>([&](auto t_) {
+        constexpr int t = decltype(t_)::value;
+        bool ok = finite(P[t][0]) && finite(P[t][1]) && finite(P[t][2]);
+        embed3_16<M, false, 10, 2>(xe[t], P[t][0], P[t][1], P[t][2], g);
+        stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]);
         if (a.use_viewdirs) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) v[c] = staged(t, 7 + c);
-          ok = ok && finite(v[0]) && finite(v[1]) && finite(v[2]);
-          embed3_16<M, false, 4, 1>(ve, v[0], v[1], v[2], g);
+          ok = ok && finite(V[t][0]) && finite(V[t][1]) && finite(V[t][2]);
+          if (same_view) {
+            stash_put(t, 2, ve0[0]);
+          } else {
+            Block ve[1];
+            embed3_16<M, false, 4, 1>(ve, V[t][0], V[t][1], V[t][2], g);
+            stash_put(t, 2, ve[0]);
+          }
         }
         if (!ok) bad |= 1u << t;
-      }
-      stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]);
-      if (a.use_viewdirs) stash_put(t, 2, ve[0]);
-    });
+      });
+#endif
+    }
 
     const float* bias = bias_lds;
     Block hA[T][NKB], hB[T][NKB];
