@@ -323,7 +323,7 @@ def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
 
 
 @pytest.mark.parametrize("tag", ["two_skips", "skip_first_and_late", "no_viewdirs_5ch", "no_viewdirs_4ch"])
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 8e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 7e-6), ("f16x3", 7e-6), ("f16", 6.5e-3), ("bf16", 5.2e-2)])   # <= 3x measured: 2.1e-6, 2.1e-6, 2.1e-3, 1.7e-2
 def test_nerf_constructor_variants(ops, golden, tag, dtype, tol):
     """The reference's whole NeRF signature (run_nerf_helpers.py:67-134) on every kernel: a `skips` list (several skips,
     a skip right after layer 0), and use_viewdirs=False -- the output_linear head with 5 or 4 channels, no view

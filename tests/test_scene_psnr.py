@@ -82,7 +82,7 @@ def fitted_band():
 
 #                                     all-ray PSNR(build || oracle) floor: ~3 dB under the value measured on MI355X (round 3)
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,floor_db", [("bf16", 28.0), ("f16", 36.0), ("f16x3", 75.0), ("f32", 75.0)])
+@pytest.mark.parametrize("dtype,floor_db", [("bf16", 31.0), ("f16", 42.0), ("f16x3", 100.0), ("f32", 100.0)])   # measured 34.5, 45.3, 110.8, 108.1
 def test_scene_psnr_within_0p05_db_of_the_reference(gpu_modules, fitted_band, dtype, floor_db):
     """PSNR(oracle fp32 || ground truth) vs PSNR(build || ground truth) on 60 rows of an 800x800 frame, DepthNet + 64
     samples/ray (BASELINE configs[1]): |delta| <= 0.05 dB for every operand type, the headline bf16 included; plus the
