@@ -433,7 +433,7 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     r0, r1 = ref["rows"]
     n = (r1 - r0) * W
     for dtype, steps in (("f16x3", 4), ("f32", 3), ("f16" if headline_dtype == "bf16" else "bf16", 5)):
-        nw, dw = fine.packed(dtype), dn.packed(dtype)
+        nw, dw = fine.packed(dtype), dn.packed(ops.depthnet_dtype_for(dtype))
         events = []
         t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events), events, device)
         elapsed, _, _ = t.run(poses, steps, 1, sync)
@@ -523,7 +523,12 @@ def main():
     _, K = synthetic.blender_intrinsics(H, W)
     poses = synthetic.render_poses(40)[:, :3, :4]
     coarse, fine, dn, params = build_modules(args.scene, device)
-    nerf_w, depth_w = fine.packed(args.dtype), dn.packed(args.dtype)
+    # the DepthNet's operand type under compute dtype X (ops.depthnet_dtype_for: f16 under bf16, same MFMA rate)
+    ops.set_compute_dtype(args.dtype)
+    depth_dtype = ops.depthnet_dtype_for(args.dtype)
+    nerf_w, depth_w = fine.packed(args.dtype), dn.packed()
+    depth_dtype = depth_w.dtype
+    ops.set_compute_dtype("f32")
     events = []
     if args.mode == "depthnet":
         rows_fn = hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1, device=device, events=events)
@@ -567,12 +572,13 @@ def main():
             "backend": args.backend if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"Lego-shaped {H}x{W} frame, DepthNet (10x256) + {args.samples} uniform samples/ray "
-                                    f"(std 0.1) through the NeRF 8x256 fine MLP" if args.mode == "depthnet" else
+            "config": {"workload": (f"Lego-shaped {H}x{W} frame, DepthNet (10x256, {depth_dtype} operands) + {args.samples} uniform "
+                                    f"samples/ray (std 0.1) through the NeRF 8x256 fine MLP ({args.dtype} operands)"
+                                    if args.mode == "depthnet" else
                                     f"Lego-shaped {H}x{W} frame, vanilla hierarchical 64 coarse + 128 importance "
                                     f"samples/ray (coarse + fine NeRF 8x256)")
                                    + f", {scene_note} ({args.scene}), spiral render poses of load_blender.py",
-                       "rays_per_step": H * W, "samples_per_ray": args.samples,
+                       "rays_per_step": H * W, "samples_per_ray": args.samples, "depthnet_operands": depth_dtype,
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
             "roofline": roofline,
         }

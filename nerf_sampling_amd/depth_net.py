@@ -70,7 +70,18 @@ class DepthNet(nn.Module):
         return len(self.hidden_sizes), widths.pop()
 
     def packed(self, dtype: Optional[str] = None) -> ops.PackedWeights:
-        name = dtype or ops.get_compute_dtype()
+        """Device weight stream (cached).  ``dtype`` given: exactly that operand type.  None: the DepthNet operand type
+        paired with the current compute dtype (ops.depthnet_dtype_for: f16 under bf16), falling back to the compute dtype
+        itself if the weights do not fit fp16's range."""
+        if dtype is None:
+            name, paired = ops.get_compute_dtype(), ops.depthnet_dtype_for()
+            if paired != name:
+                try:
+                    return self.packed(paired)
+                except NotImplementedError:
+                    pass
+        else:
+            name = dtype
         if name not in self._packed:
             self._check_supported()
             mods = (list(self.origin_layers) + list(self.direction_layers) + list(self.intersection_layers)
