@@ -103,3 +103,21 @@ def test_nerf_views_fold_matches_literal_chain(scene):
     lit = torch.nn.functional.linear(torch.cat([feat, v], -1), pd["views_linears.0.weight"], pd["views_linears.0.bias"])
     got = torch.cat([h, v], -1) @ torch.from_numpy(wo).double().T + torch.from_numpy(bo).double()
     assert float((got - lit).abs().max()) <= 2e-6 * float(lit.abs().max())
+
+
+def test_bench_flop_accounting():
+    """bench.py's three FLOP counts per NeRF sample: the reference's arithmetic (593 408 MAC), the folded
+    network without padding (roofline.frac's basis: never above the peak) and the MFMAs the kernels issue."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.nerf_flop_per_sample(8, 256, 4, "bf16")
+    assert f["reference"] == 2 * 593_408 and f["useful"] == 2 * 527_872 and f["executed"] == 2 * 535_040
+    assert bench.nerf_flop_per_sample(8, 256, 4, "f16x3")["executed"] == 3 * f["executed"]
+    f32 = bench.nerf_flop_per_sample(8, 256, 4, "f32")
+    assert f32["useful"] == f["useful"] <= f32["executed"] <= f["reference"]
+    blk = bench.roofline_block("bf16", 27.97, 640_000, 64, 8, 256, 4)
+    assert 0.60 < blk["frac"] < 0.63 and blk["frac"] < blk["executed_mfma_frac"] < blk["effective_frac_on_reference_flops"] <= 1.0
