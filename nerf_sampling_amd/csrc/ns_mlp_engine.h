@@ -738,6 +738,9 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 #ifndef NS_OB16_AHEAD
 #define NS_OB16_AHEAD 3
 #endif
+#ifndef NS_OB16_SGB
+#define NS_OB16_SGB 0   // 1: per chunk step, sched_group_barrier pattern MFMA / <=2 VALU / MFMA / DS read + VALU / MFMA / <=2 VALU / MFMA / VALU
+#endif
 constexpr int kOb16Depth = NS_OB16_DEPTH;   // A-fragment read-ahead of the 16x16x32 kernels (one wave per SIMD)
 constexpr int kOb16Ahead = NS_OB16_AHEAD;   // weight slabs in flight ahead of the open one
 
@@ -873,6 +876,18 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
         }
 #endif
       });
+#if NS_OB16_SGB
+      // ask the scheduler (IGroupLP) for an even interleave: no more than two VALU fillers between two MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+#endif
     } else {
       load_next();
     }
