@@ -9,7 +9,15 @@
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
 
+#include <cstdlib>
+
 namespace {
+
+// diagnostic switch read per launch (tests compare the two paths in one process): "1" selects the generic kernel
+inline bool ns_env_flag(const char* name) {
+  const char* v = std::getenv(name);
+  return v && v[0] == '1';
+}
 
 using namespace nsmlp;
 
@@ -22,9 +30,66 @@ using namespace nsmlp;
 #ifndef NS_NERF16_WAVES
 #define NS_NERF16_WAVES 4
 #endif
+#ifndef NS_OB16_ASM
+#define NS_OB16_ASM 1             // 1: the W = 256 hidden layers run the hand-scheduled streams of ns_ob16_asm.inc (tools/gen_ob16_asm.py)
+#endif
 constexpr int kT = NS_NERF16_T;          // 16-sample tiles per wave
 constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of activations + accumulators per wave
                                          // (8 waves x T = 2, two per SIMD in 256 registers each: measured slower)
+
+#if NS_OB16_ASM
+}  // namespace
+#include "ns_ob16_asm.inc"
+namespace {
+// One W = 256 hidden layer (ReLU) as a generated asm statement: set A (hA, AGPRs) -> set V (hB, VGPRs) or back; SKIP:
+// K-blocks 0, 1 are the embedded point xs.  Same chunk walk, ring protocol and arithmetic as layer_ob16<> +
+// convert_last16<> (bit-identical results); the ring's bookkeeping is handed over and taken back here.
+template <class M, bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_lds, int g, typename M::Block (&hA)[4][8],
+                                                 typename M::Block (&hB)[4][8], const typename M::Block (&xs)[4][2]) {
+  static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
+                "the generated streams assume the default ring");
+  using Gen = HiddenAsm<M, IN_A, SKIP>;
+  u32x4 A[32], V[32], X[8], F[4];
+  static_for<4>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (IN_A) A[8 * t + kb] = __builtin_bit_cast(u32x4, hA[t][kb].v);
+      else V[8 * t + kb] = __builtin_bit_cast(u32x4, hB[t][kb].v);
+    });
+    static_for<2>([&](auto kb_) { X[2 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, xs[t][decltype(kb_)::value].v); });
+  });
+  static_for<4>([&](auto i_) { F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
+  const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
+  const uint32_t rb0 = lane16 + ((ring.read_slot + 0) & 3) * kSlabBytes, rb1 = lane16 + ((ring.read_slot + 1) & 3) * kSlabBytes;
+  const uint32_t rb2 = lane16 + ((ring.read_slot + 2) & 3) * kSlabBytes, rb3 = lane16 + ((ring.read_slot + 3) & 3) * kSlabBytes;
+  const uint32_t bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(bias_lds))) + 16u * static_cast<uint32_t>(g);
+  const uint64_t base = reinterpret_cast<uint64_t>(ring.stream) + static_cast<uint64_t>(ring.wave) * (4 * kChunkBytes);
+  const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+  const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+  const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(ring.lds_off + static_cast<uint32_t>(ring.wave) * (4 * kChunkBytes));
+  uint32_t islab = __builtin_amdgcn_readfirstlane(ring.issue_slab);
+  uint32_t dsto = __builtin_amdgcn_readfirstlane(ring.issue_slot * kSlabBytes);
+  Gen::run(A, V, X, F, rb0, rb1, rb2, rb3, bias, static_cast<uint32_t>(ring.lane) * 16u, sbase,
+           __builtin_amdgcn_readfirstlane(ring.n_slabs), ldsw, islab, dsto);
+  ring.issue_slab = islab;
+  ring.issue_slot = dsto / kSlabBytes;
+  ring.read_slot = (ring.read_slot + Gen::kSlabs) & 3;
+  ring.nxt = ring.lds_off + ring.read_slot * kSlabBytes + static_cast<uint32_t>(ring.lane) * 16u;
+  ring.cur = ring.nxt;
+  static_for<4>([&](auto i_) { ring.f[decltype(i_)::value] = __builtin_bit_cast(typename M::AFrag, F[decltype(i_)::value]); });
+  static_for<4>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (IN_A) hB[t][kb].v = __builtin_bit_cast(typename M::AFrag, V[8 * t + kb]);
+      else hA[t][kb].v = __builtin_bit_cast(typename M::AFrag, A[8 * t + kb]);
+    });
+  });
+}
+#endif
 
 struct Nerf16Args {
   const char* stream;
@@ -46,7 +111,10 @@ struct Nerf16Args {
   float* raw;
 };
 
-template <class M, int NKB, bool EMBEDDED>   // NKB = W / 32 K-blocks of a hidden layer
+// PROD: the production network (8 x 256, skips = [4], view directions: experiments/run.py) as straight-line code whose
+// seven hidden layers are the generated asm statements -- no loop over layers, so the activation sets stay in the registers
+// the statements pin them to; every other network takes the generic, compiler-scheduled path.
+template <class M, int NKB, bool EMBEDDED, bool PROD = false>   // NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
 nerf_mlp_ob16_kernel(Nerf16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,7 +323,22 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     // have been consumed (they fed the embeddings above)
     prefetch(grp + gridDim.x);
     int l = 1;
+#if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE
+    if constexpr (PROD) {
+      static_assert(NKB == 8 && T == 4 && NWAVES == 4, "the generated streams are W = 256, four tiles, four waves");
+      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
+      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 2
+      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 3
+      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 4
+      load_xs();
+      hidden_layer_asm<M, true, true>(ring, bias, g, hA, hB, xs); bias += NSB * 16;     // 5: cat[x, h]
+      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 6
+      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
+      l = 8;
+    }
+#endif
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
+    if constexpr (!PROD) {
     for (; l + 1 < a.D; l += 2) {
       if ((a.skip_mask >> (l - 1)) & 1u) { load_xs(); layer_ob16<M, T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16<M, T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
@@ -270,7 +353,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       convert_last16<M, true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
     }
-    if (!a.use_viewdirs) {
+    }
+    if (!PROD && !a.use_viewdirs) {
       // output_linear (W -> out_ch, no activation, run_nerf_helpers.py:132-133): ONE 16-row sub-block whose raw accumulators
       // come back in `last`: row 4 g + r sits in register r of lane group g
       layer_ob16<M, T, 1, NKB, kNone>(ring, bias, g, hB, last, in_A);
@@ -303,10 +387,20 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     };
 #endif
     float sigma[T];
+    if constexpr (PROD) {   // the trunk ended in hB: (hB, ve) -> hA[0 .. NKB/2), then rgb from hA
+      auto in_Bv = [&](auto t_, auto kb_) -> const Block& {
+        constexpr int kb = decltype(kb_)::value;
+        if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
+      };
+      layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2 + 1) * 16;
+      static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
+      layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hB, last, in_A);
+    } else {
     layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
     // rgb (W/2 -> 3): rows 0..2 (lane group 0, registers 0..2)
     layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
+    }
 
     if (g == 0) {
       static_for<T>([&](auto t_) {
@@ -331,7 +425,7 @@ int ob16_program_slabs(int W, int D, uint32_t skip_mask, int use_viewdirs) {
   return n;
 }
 
-template <class M, int NKB, bool EMB>
+template <class M, int NKB, bool EMB, bool PROD = false>
 int launch(Nerf16Args& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
@@ -340,7 +434,7 @@ int launch(Nerf16Args& a, hipStream_t stream) {
     ns::set_error("ns_nerf_forward: %zu bytes of LDS needed (too deep a network for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
   }
-  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB>;
+  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB, PROD>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
   const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
@@ -354,6 +448,10 @@ int launch(Nerf16Args& a, hipStream_t stream) {
 
 template <class M, bool EMB>
 int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
+#if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE && NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
+  if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC"))
+    return launch<M, 8, EMB, true>(a, stream);   // the production network: hand-scheduled hidden layers
+#endif
   return net->width == 256 ? launch<M, 8, EMB>(a, stream) : launch<M, 4, EMB>(a, stream);
 }
 

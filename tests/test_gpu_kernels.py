@@ -292,6 +292,31 @@ def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
         assert (rms < tol).all(), (which, dtype, rms)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules, dtype, monkeypatch):
+    """The production network (8 x 256, skips = [4]) takes the kernel whose hidden layers are the generated asm streams
+    (csrc/ns_ob16_asm.inc, tools/gen_ob16_asm.py); NS_OB16_GENERIC=1 sends the same call through the compiler-scheduled
+    kernel.  Both issue the same MFMAs in the same order per accumulator, so raw must agree BIT FOR BIT -- a hazard or a
+    wrong register in the hand-written stream shows here.  Ragged counts, several groups per workgroup, both input forms."""
+    m = gpu_modules("lego_synth")
+    net = m["fine"]
+    assert (net.D, net.W, list(net.skips)) == (8, 256, [4])
+    packed = net.packed(dtype)
+    gen = torch.Generator().manual_seed(5)
+    for R, N in ((1, 1), (5, 7), (300, 64), (4100, 64), (2500, 192)):
+        pts = ((torch.rand(R, N, 3, generator=gen) * 2 - 1) * 2.5).cuda()
+        view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
+        monkeypatch.setenv("NS_OB16_GENERIC", "1")
+        ref = ops.nerf_forward(packed, pts, view)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("NS_OB16_GENERIC")
+        for _ in range(2):      # twice: the ring phase at the start of a launch does not depend on the previous one
+            got = ops.nerf_forward(packed, pts, view)
+            torch.cuda.synchronize()
+            assert torch.isfinite(got).all()
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, R, N, (got - ref).abs().max().item())
+
+
 @pytest.mark.parametrize("D,W,skip", [(2, 128, -1), (3, 256, 0), (5, 128, 3), (6, 256, 4), (7, 128, 1), (8, 256, -1), (9, 256, 4)])
 def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
     """Program logic of the 16x16x32 kernel (two layers per trip + odd tail, skip at any depth or none, both widths,
