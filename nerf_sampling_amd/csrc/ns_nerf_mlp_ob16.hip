@@ -39,7 +39,10 @@ constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of 
 
 #if NS_OB16_ASM
 }  // namespace
-#include "ns_ob16_asm.inc"
+#ifndef NS_OB16_ASM_INC
+#define NS_OB16_ASM_INC "ns_ob16_asm.inc"
+#endif
+#include NS_OB16_ASM_INC
 namespace {
 // One W = 256 hidden layer (ReLU) as a generated asm statement: set A (hA, AGPRs) -> set V (hB, VGPRs) or back; SKIP:
 // K-blocks 0, 1 are the embedded point xs.  Same chunk walk, ring protocol and arithmetic as layer_ob16<> +
@@ -480,6 +483,11 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
   const bool emb = x90_dev != nullptr;
+#ifdef NS_OB16_VARIANT_BUILD   // tools/build_asm_variant.sh: only the kernel under test is instantiated (a 20 s build)
+  if (net->dtype == NS_DTYPE_BF16 && !emb && net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs)
+    return launch<Mma16BF16, 8, false, true>(a, stream);
+  return NS_E_UNSUPPORTED;
+#endif
   if (net->dtype == NS_DTYPE_BF16) return emb ? dispatch_m<Mma16BF16, true>(net, a, stream) : dispatch_m<Mma16BF16, false>(net, a, stream);
   if (net->dtype == NS_DTYPE_F16) return emb ? dispatch_m<Mma16F16, true>(net, a, stream) : dispatch_m<Mma16F16, false>(net, a, stream);
   return NS_E_UNSUPPORTED;

@@ -60,6 +60,20 @@ def SETA(t, kb): return R('a', 32 * t + 4 * kb, 4)
 def SETV(t, kb): return R('v', 128 + 32 * t + 4 * kb, 4)
 
 
+class Opt:
+    """schedule knobs and timing-only ablations (--exp-*: results are wrong on purpose)"""
+    no_wait = False      # --exp-no-wait: no lgkmcnt waits inside the layer
+    no_dma = False       # --exp-no-dma
+    no_conv = False      # --exp-no-conv
+    no_lds = False       # --exp-no-lds: no fragment reads
+    no_barrier = False   # --exp-no-barrier
+    dma_steps = (0, 2, 4, 6)   # --dma-steps: chunk steps of a slab whose G3 carries one of the four refill pieces
+    swap_g01 = False     # --swap-g01: fragment read in G0, v_pk_max in G1
+
+
+OPT = Opt()
+
+
 class Ins:
     __slots__ = ("text", "kind", "reads", "writes", "creads", "ws")
 
@@ -108,6 +122,9 @@ class Emitter:
         if last < 0:
             return
         left = len(self.lgkm) - last - 1
+        if OPT.no_wait:
+            self.lgkm = self.lgkm[last + 1:]
+            return
         self._push(Ins(f"s_waitcnt lgkmcnt({left})", "wait"))
         self.lgkm = self.lgkm[last + 1:]
 
@@ -144,6 +161,8 @@ class Emitter:
 
     def lds_read(self, dst, addr_operand, offset):
         assert 0 <= offset < 65536
+        if OPT.no_lds and "rb" in addr_operand:
+            return
         wr = self._other(f"ds_read_b128 {fmt(dst)}, {addr_operand}" + (f" offset:{offset}" if offset else ""), "lds", (), (dst,))
         self.lgkm.append(wr)
         assert len(self.lgkm) < 15
@@ -152,6 +171,8 @@ class Emitter:
         self._push(Ins(text, "salu"))
 
     def dma(self, offset):
+        if OPT.no_dma:
+            return
         self._other(f"global_load_lds_dwordx4 {fmt(VOFF)}, %[sbase]" + (f" offset:{offset}" if offset else ""), "dma", (VOFF,), ())
 
     def drain_lds(self):
@@ -213,7 +234,13 @@ def issue_cycles(ins):
 
 
 def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
-    """One hidden layer, ReLU: set A -> set V (in_a) or set V -> set A; skip: K-blocks 0, 1 are the embedded point."""
+    """One hidden layer, ReLU: set A -> set V (in_a) or set V -> set A; skip: K-blocks 0, 1 are the embedded point.
+
+    A chunk step is  [wait] M0 <G0> M1 <G1> M2 <G2> M3 <G3>  (M = the four tiles' MFMAs of one A fragment).  What rides in
+    the gaps: G1 the fragment read three chunks ahead; the conversion of the previous sub-block, one dword per step, as a
+    three-stage pipeline so that no VALU instruction directly follows the one it depends on (v_cvt_pk in G2, v_pk_max_i16
+    in the NEXT step's G0, v_accvgpr_write in that step's G2); slab bookkeeping (vmcnt + barrier in G0 of a slab's first
+    step, its four LDS-DMA pieces in G3 of steps 0..3, scalar updates after them), the next sub-block's bias in G3."""
     nkb = nkb_h + (2 if skip else 0)
     total = nsb * nkb
     assert total % SLAB == 0 and total % DEPTH == 0
@@ -224,23 +251,39 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
     e = Emitter(dt)
     e.salu("s_mov_b32 %[keep], m0")
     e.lds_read(BIAS, "%[bias]", 0)
+
+    def dma_setup():
+        e.valu(f"v_lshl_add_u32 {fmt(VOFF)}, %[islab], 14, %[loff]", (), (VOFF,))
+        e.salu("s_add_u32 m0, %[dsto], %[ldsw]")
+
+    dma_setup()
     e.nop(VALU_WRITE_TO_XDL)             # the compiler's own VALU writes of our operands
 
-    def conv_piece(s, piece, gap_accw):
-        """dword `J` of finished sub-block s, tile t -> dword 2 (s & 1) + J of K-block s >> 1 of the output set"""
+    def piece_regs(s, piece):
         t, J = piece % T, piece // T
         a = ACC(s & 1, t)
-        tmp = TMP[piece & 1]
         dst = OUT(t, s >> 1)
-        dword = R(dst[0], dst[1] + 2 * (s & 1) + J)
-        e.valu(f"{cvt} {fmt(tmp)}, {fmt(R('v', a[1] + 2 * J))}, {fmt(R('v', a[1] + 2 * J + 1))}",
-               (R('v', a[1] + 2 * J, 2),), (tmp,))
+        return R('v', a[1] + 2 * J), R('v', a[1] + 2 * J + 1), R(dst[0], dst[1] + 2 * (s & 1) + J)
+
+    def op_cvt(s, piece, tmp):
+        lo, hi, _ = piece_regs(s, piece)
+        e.valu(f"{cvt} {fmt(tmp)}, {fmt(lo)}, {fmt(hi)}", (lo, hi), (tmp,))
+
+    def op_max(s, piece, tmp):
+        dword = piece_regs(s, piece)[2]
         if in_a:
             e.valu(f"v_pk_max_i16 {fmt(dword)}, {fmt(tmp)}, 0", (tmp,), (dword,))
         else:
             e.valu(f"v_pk_max_i16 {fmt(tmp)}, {fmt(tmp)}, 0", (tmp,), (tmp,))
-            gap_accw.append((dword, tmp))
 
+    def op_accw(s, piece, tmp):
+        if not in_a:
+            dword = piece_regs(s, piece)[2]
+            e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,))
+
+    pps = (2 * T + nkb - 1) // nkb       # conversion pieces per chunk step (1 for the hidden layers)
+    assert pps == 1
+    max_q, accw_q = [], []               # pieces whose v_pk_max / v_accvgpr_write is due
     pending_salu = []
     for p in range(total):
         sb, kc = divmod(p, nkb)
@@ -256,51 +299,67 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
         def mm(t):
             e.mfma(ACC(par, t), frag, operand(t), BIAS if kc == 0 else ACC(par, t))
 
-        accw = []
+        def g_max():
+            if max_q and not OPT.no_conv:
+                op_max(*max_q[0])
+                accw_q.append(max_q.pop(0))
+
+        def g_read():                    # fragment read-ahead (chunk p + 3 into the register of chunk p - 1)
+            q = p + DEPTH - 1
+            e.lds_read(FR(q), f"%[rb{(q // SLAB) % RING}]", (q % SLAB) * 1024)
+
         mm(0)
-        # ---- gap 0: slab bookkeeping
-        if c == 0:
+        # ---- G0
+        if c == 0 and not OPT.no_barrier:
             e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
             e.salu("s_barrier")
-            e.valu(f"v_lshl_add_u32 {fmt(VOFF)}, %[islab], 14, %[loff]", (), (VOFF,))
-            e.salu("s_add_u32 m0, %[dsto], %[ldsw]")
-            pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
-                            "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
-                            "s_and_b32 %[dsto], %[dsto], 0xc000"]
-        elif c >= 4 and pending_salu:
-            e.salu(pending_salu.pop(0))
+        g_read() if OPT.swap_g01 else g_max()
         mm(1)
-        # ---- gap 1: fragment read-ahead (chunk p + 3 into the register of chunk p - 1)
-        q = p + DEPTH - 1
-        e.lds_read(FR(q), f"%[rb{(q // SLAB) % RING}]", (q % SLAB) * 1024)
+        # ---- G1
+        g_max() if OPT.swap_g01 else g_read()
         mm(2)
-        # ---- gap 2: conversion of the previous sub-block, one piece per chunk step
-        if sb > 0:
-            pps = (2 * T + nkb - 1) // nkb
-            for i in range(pps):
-                piece = kc * pps + i
-                if piece < 2 * T:
-                    conv_piece(sb - 1, piece, accw)
+        # ---- G2
+        if sb > 0 and kc < 2 * T and not OPT.no_conv:
+            item = (sb - 1, kc, TMP[kc & 1])
+            op_cvt(*item)
+            max_q.append(item)
+        if accw_q:
+            op_accw(*accw_q.pop(0))
         mm(3)
-        # ---- gap 3
-        for dword, tmp in accw:
-            e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,))
-        if c < 4:
-            e.dma(c * 1024)
+        # ---- G3
+        if c in OPT.dma_steps:
+            e.dma(OPT.dma_steps.index(c) * 1024)
+            if c == OPT.dma_steps[-1]:
+                pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
+                                "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
+                                "s_and_b32 %[dsto], %[dsto], 0xc000"]
+        elif pending_salu:
+            e.salu(pending_salu.pop(0))
+        elif c == SLAB - 1 and p + 1 < total:
+            dma_setup()                  # address and M0 of the next slab's refill
         if kc == min(3, nkb - 1) and sb + 1 < nsb:
             e.lds_read(BIAS, "%[bias]", 64 * (sb + 1))
     assert not pending_salu
-    # ---- tail: the last sub-block
-    accw = []
-    for piece in range(2 * T):
-        conv_piece(nsb - 1, piece, accw)
-        for dword, tmp in accw:
-            e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,))
-        accw.clear()
+    # ---- tail: what is left of the conversion pipeline, then the last sub-block through 8 scratch registers (the other
+    # parity's accumulators are free), stage by stage
+    if not OPT.no_conv:
+        for it in max_q:
+            op_max(*it)
+        for it in accw_q + max_q:
+            op_accw(*it)
+        s = nsb - 1
+        scratch = [R('v', ACC((s & 1) ^ 1, 0)[1] + i) for i in range(2 * T)]
+        for piece in range(2 * T):
+            op_cvt(s, piece, scratch[piece])
+        for piece in range(2 * T):
+            op_max(s, piece, scratch[piece])
+        for piece in range(2 * T):
+            op_accw(s, piece, scratch[piece])
     e.drain_lds()
     e.salu("s_mov_b32 m0, %[keep]")
     e.nop(VALU_WRITE_TO_XDL)             # our VALU / accvgpr writes ahead of whatever MFMA the compiler issues next
-    check(e.ins)
+    if not (OPT.no_wait or OPT.no_lds):
+        check(e.ins)
     return e, slabs
 
 
@@ -361,7 +420,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nerf_sampling_amd", "csrc", "ns_ob16_asm.inc"))
     ap.add_argument("--dump", help="write the plain instruction stream of one variant (e.g. bf16_AV) here")
+    for k in ("no_wait", "no_dma", "no_conv", "no_lds", "no_barrier"):
+        ap.add_argument("--exp-" + k.replace("_", "-"), dest=k, action="store_true")
+    ap.add_argument("--dma-steps", default="0,2,4,6")
+    ap.add_argument("--swap-g01", action="store_true")
     a = ap.parse_args()
+    OPT.dma_steps = tuple(int(x) for x in a.dma_steps.split(","))
+    assert len(OPT.dma_steps) == 4 and OPT.dma_steps[-1] <= 9
+    OPT.swap_g01 = a.swap_g01
+    for k in ("no_wait", "no_dma", "no_conv", "no_lds", "no_barrier"):
+        setattr(OPT, k, getattr(a, k))
     out = [HEADER]
     for dt in ("bf16", "f16"):
         for in_a in (True, False):
