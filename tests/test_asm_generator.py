@@ -1,0 +1,67 @@
+"""tools/gen_ob16_asm.py (no GPU needed): the committed csrc/ns_ob16_asm.inc is what the generator emits, and the
+generator's independent checker pass really rejects streams that break a hazard rule or read an LDS result early."""
+import importlib.util
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN = os.path.join(ROOT, "tools", "gen_ob16_asm.py")
+INC = os.path.join(ROOT, "nerf_sampling_amd", "csrc", "ns_ob16_asm.inc")
+
+
+@pytest.fixture(scope="module")
+def gen():
+    spec = importlib.util.spec_from_file_location("gen_ob16_asm", GEN)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_committed_streams_are_the_generator_output(tmp_path):
+    out = tmp_path / "x.inc"
+    subprocess.run([sys.executable, GEN, "-o", str(out)], check=True, capture_output=True)
+    assert out.read_text() == open(INC).read(), "regenerate: python tools/gen_ob16_asm.py"
+
+
+@pytest.mark.parametrize("in_a", [True, False])
+@pytest.mark.parametrize("skip", [False, True])
+def test_stream_shape(gen, in_a, skip):
+    e, slabs = gen.gen_layer("bf16", in_a, skip)
+    nkb = 10 if skip else 8
+    assert slabs == nkb
+    kinds = [i.kind for i in e.ins]
+    assert kinds.count("mfma") == 4 * 16 * nkb                      # four tiles x 16 sub-blocks x K-blocks
+    assert kinds.count("dma") == 4 * slabs                          # every slab refilled by four pieces per wave
+    assert sum("s_barrier" in i.text for i in e.ins) == slabs
+    assert kinds.count("lds") == 16 * nkb + 16                      # one fragment per chunk + one bias tuple per sub-block
+    valu = [i.text.split()[0] for i in e.ins if i.kind == "valu"]
+    assert valu.count("v_cvt_pk_bf16_f32") == 128 and valu.count("v_pk_max_i16") == 128   # one per output dword
+    assert valu.count("v_accvgpr_write_b32") == (0 if in_a else 128)
+    # every accumulator chain is K-ordered: the MFMAs writing one accumulator read the K-blocks in ascending order
+    gen.check(e.ins)
+
+
+def test_checker_rejects_broken_streams(gen):
+    e, _ = gen.gen_layer("bf16", True, False)
+    ins = list(e.ins)
+    # (1) a conversion moved right behind the MFMA that produces its input
+    k = next(n for n, i in enumerate(ins) if i.kind == "valu" and i.text.startswith("v_cvt_pk"))
+    src = ins[k].reads
+    w = max(n for n in range(k) if ins[n].kind == "mfma" and ins[n].writes & src)
+    bad = ins[:w + 1] + [ins[k]] + ins[w + 1:k] + ins[k + 1:]
+    with pytest.raises(AssertionError, match="MFMA D->valu"):
+        gen.check(bad)
+    # (2) a fragment wait dropped
+    k = next(n for n, i in enumerate(ins) if i.kind == "wait" and n > 40)
+    with pytest.raises(AssertionError, match="LDS result not waited for"):
+        gen.check(ins[:k] + ins[k + 1:])
+    # (3) a VALU write directly in front of the MFMA that reads it
+    k = next(n for n, i in enumerate(ins) if i.kind == "valu" and i.text.startswith("v_pk_max"))
+    dst = ins[k].writes
+    fake = gen.Ins("v_mfma_f32_16x16x32_bf16 v[0:3], v[32:35], v[128:131], v[0:3]", "mfma",
+                   reads=(gen.R('v', 32, 4), next(gen.R(f, b, 1) for f, b in dst)), writes=(gen.R('v', 0, 4),), creads=(gen.R('v', 0, 4),))
+    with pytest.raises(AssertionError, match="VALU->MFMA"):
+        gen.check(ins[:k + 1] + [fake])

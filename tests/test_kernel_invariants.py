@@ -74,9 +74,11 @@ def _functions(dis):
 def test_nerf16_kernels_use_no_scratch_and_no_full_dma_wait(nerf16_isa):
     dis, notes = nerf16_isa
     fns = {k: v for k, v in _functions(dis).items() if "nerf_mlp_ob16_kernel" in k}
-    # the rays -> raw kernels (EMBEDDED = false: mangled "...ELb0EEE"), bf16 and f16, W = 256 and 128
-    main = {k: v for k, v in fns.items() if "ELb0EE" in k}
-    assert len(main) == 4, sorted(fns)
+    # the rays -> raw kernels (EMBEDDED = false: mangled "...ELb0ELb<PROD>EEE"), bf16 and f16: the generic program at
+    # W = 256 and 128, and the production program (hand-scheduled hidden layers) at W = 256
+    main = {k: v for k, v in fns.items() if re.search(r"ELi[48]ELb0ELb[01]EEE", k)}
+    assert len(main) == 6, sorted(fns)
+    assert len(fns) == 12, sorted(fns)
     for name, ins in main.items():
         text = "\n".join(ins)
         assert "scratch_" not in text, f"{name}: scratch access in the kernel"
@@ -92,6 +94,31 @@ def test_nerf16_kernels_use_no_scratch_and_no_full_dma_wait(nerf16_isa):
         m = re.search(re.escape(name) + r".*?\.private_segment_fixed_size:\s*(\d+)", notes, re.S)
         if m:
             assert int(m.group(1)) == 0
+
+
+def test_production_kernel_is_straight_line_hand_scheduled_code(nerf16_isa):
+    """The production program (8 x 256, skips = [4]): every MFMA of a group pass appears exactly once (no loop over layers:
+    4 180 per 64 samples), and between the seven generated layer statements the compiler moves no
+    activation register (the statements pin the two activation sets to a[0:127] / v[128:255]; a copy there would be 128
+    v_accvgpr / v_mov instructions per layer)."""
+    dis, _ = nerf16_isa
+    fns = {k: v for k, v in _functions(dis).items() if re.search(r"Mma16BF16ELi8ELb0ELb1EEE", k)}
+    assert len(fns) == 1, sorted(fns)
+    ins = [i.split("//")[0].strip() for i in next(iter(fns.values()))]
+    assert sum("v_mfma_f32_16x16x32_bf16" in i for i in ins) == 4180
+    # a generated statement opens with its first bias read into v[48:51]
+    starts = [n for n, i in enumerate(ins) if re.match(r"ds_read_b128 v\[48:51\], v\d+$", i)]
+    assert len(starts) == 7, starts
+    for a, b in zip(starts, starts[1:]):
+        seg = ins[a:b]
+        n_mfma = sum("v_mfma" in i for i in seg)
+        assert n_mfma in (512, 640)
+        copies = sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg)
+        assert copies <= 8, (a, b, copies)
+        # what the statements themselves need: one v_accvgpr_write per output dword in the V -> A layers, none in A -> V
+        assert sum(i.startswith("v_accvgpr_write") for i in seg) in (0, 128)
+        # hazard pads are the exception in the hand-written stream (the compiled layers carry ~0.2 s_nop per MFMA)
+        assert sum(i.startswith("s_nop") for i in seg) <= 12
 
 
 def _check_mlp_kernels(dis, notes, name_part, n_expected, mfma_pat, min_mfma):
