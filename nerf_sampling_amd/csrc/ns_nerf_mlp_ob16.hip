@@ -50,10 +50,7 @@ namespace {
 template <class M, bool IN_A, bool SKIP, class PipeT>
 __device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_lds, int g, typename M::Block (&hA)[4][8],
                                                  typename M::Block (&hB)[4][8], const typename M::Block (&xs)[4][2]) {
-  static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
-                "the generated streams assume the default ring");
-  using Gen = HiddenAsm<M, IN_A, SKIP>;
-  u32x4 A[32], V[32], X[8], F[4];
+  u32x4 A[32], V[32], X[8];
   static_for<4>([&](auto t_) {
     constexpr int t = decltype(t_)::value;
     static_for<8>([&](auto kb_) {
@@ -63,26 +60,7 @@ __device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_
     });
     static_for<2>([&](auto kb_) { X[2 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, xs[t][decltype(kb_)::value].v); });
   });
-  static_for<4>([&](auto i_) { F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
-  const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
-  const uint32_t rb0 = lane16 + ((ring.read_slot + 0) & 3) * kSlabBytes, rb1 = lane16 + ((ring.read_slot + 1) & 3) * kSlabBytes;
-  const uint32_t rb2 = lane16 + ((ring.read_slot + 2) & 3) * kSlabBytes, rb3 = lane16 + ((ring.read_slot + 3) & 3) * kSlabBytes;
-  const uint32_t bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(bias_lds))) + 16u * static_cast<uint32_t>(g);
-  const uint64_t base = reinterpret_cast<uint64_t>(ring.stream) + static_cast<uint64_t>(ring.wave) * (4 * kChunkBytes);
-  const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
-  const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
-  const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
-  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(ring.lds_off + static_cast<uint32_t>(ring.wave) * (4 * kChunkBytes));
-  uint32_t islab = __builtin_amdgcn_readfirstlane(ring.issue_slab);
-  uint32_t dsto = __builtin_amdgcn_readfirstlane(ring.issue_slot * kSlabBytes);
-  Gen::run(A, V, X, F, rb0, rb1, rb2, rb3, bias, static_cast<uint32_t>(ring.lane) * 16u, sbase,
-           __builtin_amdgcn_readfirstlane(ring.n_slabs), ldsw, islab, dsto);
-  ring.issue_slab = islab;
-  ring.issue_slot = dsto / kSlabBytes;
-  ring.read_slot = (ring.read_slot + Gen::kSlabs) & 3;
-  ring.nxt = ring.lds_off + ring.read_slot * kSlabBytes + static_cast<uint32_t>(ring.lane) * 16u;
-  ring.cur = ring.nxt;
-  static_for<4>([&](auto i_) { ring.f[decltype(i_)::value] = __builtin_bit_cast(typename M::AFrag, F[decltype(i_)::value]); });
+  hidden_asm_run<M, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
   static_for<4>([&](auto t_) {
     constexpr int t = decltype(t_)::value;
     static_for<8>([&](auto kb_) {

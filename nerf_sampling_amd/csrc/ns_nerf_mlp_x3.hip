@@ -8,12 +8,59 @@
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace nsmlp;
 
 constexpr int kT = 2;        // 16-sample tiles per wave (hi + lo activation blocks: half the tiles of the plain kernel)
 constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + accumulators per wave
+#ifndef NS_OB16_ASM
+#define NS_OB16_ASM 1        // 1: the production network's hidden layers run the generated streams of ns_ob16_asm.inc
+#endif
+
+inline bool ns_env_flag(const char* name) {   // diagnostic switch read per launch: NS_OB16_GENERIC=1 selects the generic kernel
+  const char* v = std::getenv(name);
+  return v && v[0] == '1';
+}
+
+#if NS_OB16_ASM
+}  // namespace
+#ifndef NS_OB16_ASM_INC
+#define NS_OB16_ASM_INC "ns_ob16_asm.inc"
+#endif
+#include NS_OB16_ASM_INC
+namespace {
+// one W = 256 hidden layer of the split-operand network as a generated statement (see ns_nerf_mlp_ob16.hip): the (hi, lo)
+// blocks of set A / set V are the tuple pairs [tile][kb][half] of the register map
+template <bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_layer_asm_x3(PipeT& ring, const float* bias_lds, int g, Mma16F16x3::Block (&hA)[2][8],
+                                                    Mma16F16x3::Block (&hB)[2][8], const Mma16F16x3::Block (&xs)[2][2]) {
+  u32x4 A[32], V[32], X[8];
+  static_for<2>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value, k = 2 * (8 * t + kb);
+      if constexpr (IN_A) { A[k] = __builtin_bit_cast(u32x4, hA[t][kb].hi); A[k + 1] = __builtin_bit_cast(u32x4, hA[t][kb].lo); }
+      else { V[k] = __builtin_bit_cast(u32x4, hB[t][kb].hi); V[k + 1] = __builtin_bit_cast(u32x4, hB[t][kb].lo); }
+    });
+    static_for<2>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value, k = 2 * (2 * t + kb);
+      X[k] = __builtin_bit_cast(u32x4, xs[t][kb].hi); X[k + 1] = __builtin_bit_cast(u32x4, xs[t][kb].lo);
+    });
+  });
+  hidden_asm_run<Mma16F16x3, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
+  static_for<2>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value, k = 2 * (8 * t + kb);
+      if constexpr (IN_A) { hB[t][kb].hi = __builtin_bit_cast(f16x8, V[k]); hB[t][kb].lo = __builtin_bit_cast(f16x8, V[k + 1]); }
+      else { hA[t][kb].hi = __builtin_bit_cast(f16x8, A[k]); hA[t][kb].lo = __builtin_bit_cast(f16x8, A[k + 1]); }
+    });
+  });
+}
+#endif
 
 struct NerfX3Args {
   const char* stream;
@@ -35,7 +82,9 @@ struct NerfX3Args {
   float* raw;
 };
 
-template <int NKB, bool EMBEDDED>   // NKB = W / 32 K-blocks of a hidden layer
+// PROD: the production network (8 x 256, skips = [4], view directions) as straight-line code over the generated layer
+// statements, as in ns_nerf_mlp_ob16.hip
+template <int NKB, bool EMBEDDED, bool PROD = false>   // NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
 nerf_mlp_x3_kernel(NerfX3Args a) {
   using M = Mma16F16x3;
@@ -170,7 +219,22 @@ if (a.use_viewdirs) {
     // have been consumed (they fed the embeddings above)
     prefetch(grp + gridDim.x);
     int l = 1;
+#if NS_OB16_ASM
+    if constexpr (PROD) {
+      static_assert(NKB == 8 && T == 2 && NWAVES == 4, "the generated streams are W = 256, two split tiles, four waves");
+      hidden_layer_asm_x3<true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
+      hidden_layer_asm_x3<false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 2
+      hidden_layer_asm_x3<true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 3
+      hidden_layer_asm_x3<false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 4
+      load_xs();
+      hidden_layer_asm_x3<true, true>(ring, bias, g, hA, hB, xs); bias += NSB * 16;     // 5: cat[x, h]
+      hidden_layer_asm_x3<false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 6
+      hidden_layer_asm_x3<true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
+      l = 8;
+    }
+#endif
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
+    if constexpr (!PROD) {
     for (; l + 1 < a.D; l += 2) {
       if ((a.skip_mask >> (l - 1)) & 1u) { load_xs(); layer_ob16x3<T, NSB, NKB + 2, true>(ring, bias, g, hB, last, in_xA); }
       else layer_ob16x3<T, NSB, NKB, true>(ring, bias, g, hB, last, in_A);
@@ -185,7 +249,8 @@ if (a.use_viewdirs) {
       convert_last16x3<true, T, NSB>(hB, last); bias += NSB * 16;
       static_for<T>([&](auto t_) { static_for<NKB>([&](auto b_) { hA[decltype(t_)::value][decltype(b_)::value] = hB[decltype(t_)::value][decltype(b_)::value]; }); });
     }
-    if (!a.use_viewdirs) {
+    }
+    if (!PROD && !a.use_viewdirs) {
       // output_linear (W -> out_ch, no activation, run_nerf_helpers.py:132-133): one 16-row sub-block, raw accumulators in
       // `last`: row 4 g + r sits in register r of lane group g
       layer_ob16x3<T, 1, NKB, kNone>(ring, bias, g, hB, last, in_A);
@@ -211,10 +276,20 @@ if (a.use_viewdirs) {
       if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
     };
     float sigma[T];
+    if constexpr (PROD) {   // the trunk ended in hB: (hB, ve) -> hA[0 .. NKB/2), then rgb from hA
+      auto in_Bv = [&](auto t_, auto kb_) -> const Block& {
+        constexpr int kb = decltype(kb_)::value;
+        if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
+      };
+      layer_ob16x3<T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2 + 1) * 16;
+      static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
+      layer_ob16x3<T, 1, NKB / 2, kNone>(ring, bias, g, hB, last, in_A);
+    } else {
     layer_ob16x3<T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
     // rgb (W/2 -> 3): rows 0..2 (lane group 0, registers 0..2)
     layer_ob16x3<T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
+    }
 
     if (g == 0) {
       static_for<T>([&](auto t_) {
@@ -237,13 +312,13 @@ int x3_program_slabs(int W, int D, uint32_t skip_mask, int use_viewdirs) {   // 
   return n;
 }
 
-template <int NKB, bool EMB>
+template <int NKB, bool EMB, bool PROD = false>
 int launch(NerfX3Args& a, hipStream_t stream) {
   using M = Mma16F16x3;
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 2048 +
                      static_cast<size_t>(kWaves) * 10 * 256;   // ring | bias | embedding stash (hi, lo) | input staging
-  auto kern = nerf_mlp_x3_kernel<NKB, EMB>;
+  auto kern = nerf_mlp_x3_kernel<NKB, EMB, PROD>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
   const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
@@ -274,6 +349,10 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
   const bool emb = x90_dev != nullptr, wide = net->width == 256;
+#if NS_OB16_ASM
+  if (wide && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC"))
+    return emb ? launch<8, true, true>(a, stream) : launch<8, false, true>(a, stream);   // the production network
+#endif
   if (emb) return wide ? launch<8, true>(a, stream) : launch<4, true>(a, stream);
   return wide ? launch<8, false>(a, stream) : launch<4, false>(a, stream);
 }

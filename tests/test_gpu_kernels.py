@@ -292,7 +292,7 @@ def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
         assert (rms < tol).all(), (which, dtype, rms)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3"])
 def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules, dtype, monkeypatch):
     """The production network (8 x 256, skips = [4]) takes the kernel whose hidden layers are the generated asm streams
     (csrc/ns_ob16_asm.inc, tools/gen_ob16_asm.py); NS_OB16_GENERIC=1 sends the same call through the compiler-scheduled

@@ -363,8 +363,157 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
     return e, slabs
 
 
+def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
+    """One hidden layer of the split-operand kernel (f16x3: x = hi + lo in fp16, three MFMAs per product term), T = 2
+    tiles: layer_ob16x3<> + convert_last16x3<> of ns_mlp_engine.h as one statement.  A sub-block is 2 nkb chunks: chunk
+    2 kc is W_hi of K-block kc (MFMAs on x_hi and x_lo of both tiles), chunk 2 kc + 1 is W_lo (x_hi only).  Same register
+    map as the 16-bit layers with (hi, lo) tuple pairs: set element [tile][kb][half] = base + 64 tile + 8 kb + 4 half;
+    accumulators v[0:15], conversion scratch v[16:31].  A finished dword pair costs ten VALU instructions (NaN-keeping
+    ReLU by compare + select, fp16 hi, its fp32 image, the remainder, fp16 lo), twelve with the AGPR writes; they are
+    queued per sub-block and issued one or two per MFMA gap of the following sub-block."""
+    TX = 2
+    nkb = nkb_h + (2 if skip else 0)
+    cps = 2 * nkb
+    total = nsb * cps
+    assert total % SLAB == 0
+    slabs = total // SLAB
+
+    def ACCX(par, t): return R('v', 8 * par + 4 * t, 4)
+    def SETX(f, base, t, kb, half): return R(f, base + 64 * t + 8 * kb + 4 * half, 4)
+    def IN(t, kb, half): return SETX('a', 0, t, kb, half) if in_a else SETX('v', 128, t, kb, half)
+    def OUT(t, kb, half): return SETX('v', 128, t, kb, half) if in_a else SETX('a', 0, t, kb, half)
+    def XSX(t, kb, half): return R('v', 64 + 16 * t + 8 * kb + 4 * half, 4)
+
+    e = Emitter("f16")
+    e.salu("s_mov_b32 %[keep], m0")
+    e.lds_read(BIAS, "%[bias]", 0)
+
+    def dma_setup():
+        e.valu(f"v_lshl_add_u32 {fmt(VOFF)}, %[islab], 14, %[loff]", (), (VOFF,))
+        e.salu("s_add_u32 m0, %[dsto], %[ldsw]")
+
+    dma_setup()
+    e.nop(VALU_WRITE_TO_XDL)
+
+    def piece_ops(s, pi):
+        """micro-ops (closures) converting dword pair J of tile t of finished sub-block s;  pi = J * TX + t"""
+        t, J = pi % TX, pi // TX
+        acc = ACCX(s & 1, t)
+        a, b = R('v', acc[1] + 2 * J), R('v', acc[1] + 2 * J + 1)
+        ba, bb, ht, lt = (R('v', 16 + 4 * pi + i) for i in range(4))
+        ohi, olo = OUT(t, s >> 1, 0), OUT(t, s >> 1, 1)
+        dw = 2 * (s & 1) + J
+        dhi, dlo = R(ohi[0], ohi[1] + dw), R(olo[0], olo[1] + dw)
+        H, L = (dhi, dlo) if in_a else (ht, lt)
+        ops = []
+        for x in (a, b):                 # x < 0 ? 0 : x, NaN stays NaN (as torch.relu)
+            ops.append(lambda x=x: e.valu(f"v_cmp_ngt_f32_e32 vcc, 0, {fmt(x)}", (x,), ()))
+            ops.append(lambda x=x: e.valu(f"v_cndmask_b32_e32 {fmt(x)}, 0, {fmt(x)}, vcc", (x,), (x,)))
+        ops.append(lambda: e.valu(f"v_cvt_pk_f16_f32 {fmt(H)}, {fmt(a)}, {fmt(b)}", (a, b), (H,)))
+        ops.append(lambda: e.valu(f"v_cvt_f32_f16_e32 {fmt(ba)}, {fmt(H)}", (H,), (ba,)))
+        ops.append(lambda: e.valu(f"v_cvt_f32_f16_sdwa {fmt(bb)}, {fmt(H)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", (H,), (bb,)))
+        ops.append(lambda: e.valu(f"v_sub_f32_e32 {fmt(a)}, {fmt(a)}, {fmt(ba)}", (a, ba), (a,)))      # exact: hi is the nearest fp16
+        ops.append(lambda: e.valu(f"v_sub_f32_e32 {fmt(b)}, {fmt(b)}, {fmt(bb)}", (b, bb), (b,)))
+        ops.append(lambda: e.valu(f"v_cvt_pk_f16_f32 {fmt(L)}, {fmt(a)}, {fmt(b)}", (a, b), (L,)))
+        if not in_a:
+            ops.append(lambda: e.valu(f"v_accvgpr_write_b32 {fmt(dhi)}, {fmt(ht)}", (ht,), (dhi,)))
+            ops.append(lambda: e.valu(f"v_accvgpr_write_b32 {fmt(dlo)}, {fmt(lt)}", (lt,), (dlo,)))
+        return ops
+
+    conv_q = []
+    pending_salu = []
+
+    def conv(n):
+        for _ in range(n):
+            if conv_q and not OPT.no_conv:
+                conv_q.pop(0)()
+
+    for p in range(total):
+        sb, cc = divmod(p, cps)
+        kc, part = divmod(cc, 2)
+        par = sb & 1
+        c = p % SLAB
+        frag = FR(p)
+
+        def operand(t, half):
+            if skip:
+                return XSX(t, kc, half) if kc < 2 else IN(t, kc - 2, half)
+            return IN(t, kc, half)
+
+        first = [True] * TX
+
+        def mm(t, half):
+            cin = BIAS if (cc == 0 and first[t]) else ACCX(par, t)
+            first[t] = False
+            e.mfma(ACCX(par, t), frag, operand(t, half), cin)
+
+        def g_read():
+            q = p + DEPTH - 1
+            e.lds_read(FR(q), f"%[rb{(q // SLAB) % RING}]", (q % SLAB) * 1024)
+
+        def g_misc():
+            nonlocal pending_salu
+            if c in OPT.dma_steps:
+                e.dma(OPT.dma_steps.index(c) * 1024)
+                if c == OPT.dma_steps[-1]:
+                    pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
+                                    "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
+                                    "s_and_b32 %[dsto], %[dsto], 0xc000"]
+            elif pending_salu:
+                e.salu(pending_salu.pop(0))
+            elif c == SLAB - 1 and p + 1 < total:
+                dma_setup()
+            if cc == min(6, cps - 1) and sb + 1 < nsb:
+                e.lds_read(BIAS, "%[bias]", 64 * (sb + 1))
+
+        ncv = 0 if cc == 0 else 1        # the first chunk of a sub-block leaves the finished accumulators their 8 wait states
+        if part == 0:                    # W_hi: x_hi and x_lo of both tiles (per accumulator: hi before lo, as the compiled layer)
+            mm(0, 0)
+            if c == 0 and not OPT.no_barrier:
+                e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
+                e.salu("s_barrier")
+            conv(ncv)
+            mm(1, 0)
+            g_read()
+            conv(ncv)
+            mm(0, 1)
+            conv(2 * ncv)
+            mm(1, 1)
+            conv(ncv)
+            g_misc()
+        else:                            # W_lo: x_hi only
+            mm(0, 0)
+            conv(ncv)
+            mm(1, 0)
+            g_read()
+            conv(ncv)
+            g_misc()
+        if cc == cps - 1 and sb + 1 < nsb:
+            assert not conv_q or OPT.no_conv, "conversion queue did not drain within one sub-block"
+            for pi in range(2 * TX):
+                conv_q.extend(piece_ops(sb, pi))
+    assert not pending_salu
+    if not OPT.no_conv:
+        for pi in range(2 * TX):         # tail: the last sub-block, the pieces' chains interleaved
+            conv_q.extend(piece_ops(nsb - 1, pi))
+        chains = [conv_q[i * (len(conv_q) // (2 * TX)):(i + 1) * (len(conv_q) // (2 * TX))] for i in range(2 * TX)]
+        # (vcc couples a compare to its select: pairs stay together, chains advance two ops at a time for the ReLU part)
+        order = []
+        for k in range(0, len(chains[0]), 2):
+            for ch in chains:
+                order.extend(ch[k:k + 2])
+        for op in order:
+            op()
+    e.drain_lds()
+    e.salu("s_mov_b32 m0, %[keep]")
+    e.nop(VALU_WRITE_TO_XDL)
+    if not (OPT.no_wait or OPT.no_lds):
+        check(e.ins)
+    return e, slabs
+
+
 def cpp_function(name, dt, in_a, skip, e, slabs):
-    m = "Mma16BF16" if dt == "bf16" else "Mma16F16"
+    m = {"bf16": "Mma16BF16", "f16": "Mma16F16", "f16x3": "Mma16F16x3"}[dt]
     text = "\\n\\t\"\n      \"".join(i.text for i in e.ins)
     outs, ins = [], []
     for t in range(T):
@@ -385,7 +534,7 @@ def cpp_function(name, dt, in_a, skip, e, slabs):
                 ins.append(f'"{{{fmt(XS(t, kb))}}}"(X[{2 * t + kb}])')
     ins += ['[rb0] "v"(rb0)', '[rb1] "v"(rb1)', '[rb2] "v"(rb2)', '[rb3] "v"(rb3)', '[bias] "v"(bias)', '[loff] "v"(loff)',
             '[sbase] "s"(sbase)', '[nsl] "s"(nsl)', '[ldsw] "s"(ldsw)']
-    clob = ['"memory"', '"scc"'] + [f'"v{i}"' for i in list(range(0, 32)) + list(range(48, 56))]
+    clob = ['"memory"', '"scc"', '"vcc"'] + [f'"v{i}"' for i in list(range(0, 32)) + list(range(48, 56))]
     n_mfma = sum(i.kind == "mfma" for i in e.ins)
     cyc = issue_cycles(e.ins)
     return f"""
@@ -412,7 +561,45 @@ HEADER = """// GENERATED by tools/gen_ob16_asm.py -- do not edit; regenerate wit
 #pragma once
 namespace nsmlp {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct Mma16BF16;
+struct Mma16F16;
+struct Mma16F16x3;
 template <class M, bool IN_A, bool SKIP> struct HiddenAsm;
+"""
+
+
+FOOTER = """
+// Hands the weight ring's bookkeeping to one generated layer statement and takes it back: set A (a[0:127]) -> set V
+// (v[128:255]) or back; X = the skip layer's embedded point.  Same chunk walk, ring protocol and arithmetic as the
+// compiled layer_ob16<> / layer_ob16x3<> + convert_last16*<>, so results are bit-identical.
+template <class M, bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[32], u32x4 (&V)[32], const u32x4 (&X)[8]) {
+  static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
+                "the generated streams assume the default ring");
+  using Gen = HiddenAsm<M, IN_A, SKIP>;
+  u32x4 F[4];
+  static_for<4>([&](auto i_) { F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
+  const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
+  const uint32_t rb0 = lane16 + ((ring.read_slot + 0) & 3) * kSlabBytes, rb1 = lane16 + ((ring.read_slot + 1) & 3) * kSlabBytes;
+  const uint32_t rb2 = lane16 + ((ring.read_slot + 2) & 3) * kSlabBytes, rb3 = lane16 + ((ring.read_slot + 3) & 3) * kSlabBytes;
+  const uint32_t bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(bias_lds))) + 16u * static_cast<uint32_t>(g);
+  const uint64_t base = reinterpret_cast<uint64_t>(ring.stream) + static_cast<uint64_t>(ring.wave) * (4 * kChunkBytes);
+  const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+  const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+  const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(ring.lds_off + static_cast<uint32_t>(ring.wave) * (4 * kChunkBytes));
+  uint32_t islab = __builtin_amdgcn_readfirstlane(ring.issue_slab);
+  uint32_t dsto = __builtin_amdgcn_readfirstlane(ring.issue_slot * kSlabBytes);
+  Gen::run(A, V, X, F, rb0, rb1, rb2, rb3, bias, static_cast<uint32_t>(ring.lane) * 16u, sbase,
+           __builtin_amdgcn_readfirstlane(ring.n_slabs), ldsw, islab, dsto);
+  ring.issue_slab = islab;
+  ring.issue_slot = dsto / kSlabBytes;
+  ring.read_slot = (ring.read_slot + Gen::kSlabs) & 3;
+  ring.nxt = ring.lds_off + ring.read_slot * kSlabBytes + static_cast<uint32_t>(ring.lane) * 16u;
+  ring.cur = ring.nxt;
+  static_for<4>([&](auto i_) { ring.f[decltype(i_)::value] = __builtin_bit_cast(typename M::AFrag, F[decltype(i_)::value]); });
+}
+}  // namespace nsmlp
 """
 
 
@@ -441,7 +628,16 @@ def main():
                       f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
                 if a.dump and a.dump == f"{dt}_{'AV' if in_a else 'VA'}{'_skip' if skip else ''}":
                     open(a.dump + ".s", "w").write("\n".join(i.text for i in e.ins) + "\n")
-    out.append("}  // namespace nsmlp\n")
+    for in_a in (True, False):
+        for skip in (False, True):
+            e, slabs = gen_layer_x3(in_a, skip)
+            name = f"f16x3 {'A->V' if in_a else 'V->A'}{' skip' if skip else ''}"
+            out.append(cpp_function(name, "f16x3", in_a, skip, e, slabs))
+            print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 768), "
+                  f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
+            if a.dump and a.dump == f"f16x3_{'AV' if in_a else 'VA'}{'_skip' if skip else ''}":
+                open(a.dump + ".s", "w").write("\n".join(i.text for i in e.ins) + "\n")
+    out.append(FOOTER)
     with open(a.o, "w") as f:
         f.write("".join(out))
 
