@@ -144,7 +144,11 @@ def test_depthnet16_kernels_use_no_scratch_and_no_full_dma_wait():
 
 def test_nerf_x3_kernels_use_no_scratch_and_no_full_dma_wait():
     dis, notes = _isa_of(b"nerf_mlp_x3_kernel")
-    fns = {k: v for k, v in _functions(dis).items() if "nerf_mlp_x3_kernel" in k and "ELb0EE" in k}
-    assert len(fns) == 2, sorted(fns)
+    # rays -> raw kernels (EMBEDDED = false): the generic program at W = 256 / 128 and the production program (generated
+    # hidden layers) at W = 256
+    fns = {k: v for k, v in _functions(dis).items() if re.search(r"nerf_mlp_x3_kernelILi[48]ELb0ELb[01]EEE", k)}
+    assert len(fns) == 3, sorted(fns)
     _check_mlp_kernels("\n".join(f"0000 <{k}>:\n" + "\n".join("\t" + i for i in v) for k, v in fns.items()), notes,
-                       "nerf_mlp_x3_kernel", 2, "v_mfma_f32_16x16x32_f16", 1500)
+                       "nerf_mlp_x3_kernel", 3, "v_mfma_f32_16x16x32_f16", 1500)
+    prod = [i.split("//")[0].strip() for k, v in fns.items() if "ILi8ELb0ELb1EEE" in k for i in v]
+    assert sum("v_mfma_f32_16x16x32_f16" in i for i in prod) == 3 * 4180 // 2    # straight-line: three MFMAs per product term, two tiles
