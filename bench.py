@@ -556,11 +556,11 @@ def main():
                               fine.D, fine.W, 4)
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (PMC counters cannot
     # be read from inside the process); only quoted for the exact workload and build they were collected on
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r03b_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
         roofline["traffic"] = json.load(open(tpath))["hbm_bytes_per_launch"]
-        roofline["traffic_source"] = "profiles/r03_traffic_nerf_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, not live)"
+        roofline["traffic_source"] = "profiles/r03b_traffic_nerf_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, not live)"
 
     if rank == 0:
         rays = H * W * args.steps

@@ -11,19 +11,19 @@ for name in "$@"; do
   out=$root/gpurun_out/pmcclk_$name
   rm -rf $out; mkdir -p $out
   timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
-    --kernel-trace --output-format csv -d $out -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-api-path > $out/run.log 2>&1 || { tail -5 $out/run.log; echo "$name failed"; continue; }
+    --kernel-trace --output-format csv -d $out -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-api-path ${PMC_BENCH_ARGS} > $out/run.log 2>&1 || { tail -5 $out/run.log; echo "$name failed"; continue; }
   python - "$name" "$out" <<'PY'
 import csv, glob, collections, sys
 name, out = sys.argv[1:]
 acc = collections.defaultdict(list)
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "nerf_mlp_ob16" in r["Kernel_Name"]:
+        if "nerf_mlp_ob16" in r["Kernel_Name"] or "nerf_mlp_x3" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = []
 for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "nerf_mlp_ob16" in r["Kernel_Name"]:
+        if "nerf_mlp_ob16" in r["Kernel_Name"] or "nerf_mlp_x3" in r["Kernel_Name"]:
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 top = lambda v: sorted(v)[len(v) // 2:]          # full-frame launches only
 m = {k: sum(top(v)) / len(top(v)) for k, v in acc.items()}
