@@ -11,67 +11,9 @@
 
 #include <cstdlib>
 
-namespace {
-
-// diagnostic switch read per launch (tests compare the two paths in one process): "1" selects the generic kernel
-inline bool ns_env_flag(const char* name) {
-  const char* v = std::getenv(name);
-  return v && v[0] == '1';
-}
-
-using namespace nsmlp;
-
-#ifndef NS_NERF16_T
-#define NS_NERF16_T 4
-#endif
-#ifndef NS_NERF16_RELOAD_ONCE
-#define NS_NERF16_RELOAD_ONCE 1   // 1: stashed embeddings come back from LDS once per layer, not once per sub-block
-#endif
-#ifndef NS_NERF16_WAVES
-#define NS_NERF16_WAVES 4
-#endif
-#ifndef NS_OB16_ASM
-#define NS_OB16_ASM 1             // 1: the W = 256 hidden layers run the hand-scheduled streams of ns_ob16_asm.inc (tools/gen_ob16_asm.py)
-#endif
-constexpr int kT = NS_NERF16_T;          // 16-sample tiles per wave
-constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of activations + accumulators per wave
-                                         // (8 waves x T = 2, two per SIMD in 256 registers each: measured slower, DESIGN.md section 6)
-
-#if NS_OB16_ASM
-}  // namespace
-#ifndef NS_OB16_ASM_INC
-#define NS_OB16_ASM_INC "ns_ob16_asm.inc"
-#endif
-#include NS_OB16_ASM_INC
-namespace {
-// One W = 256 hidden layer (ReLU) as a generated asm statement: set A (hA, AGPRs) -> set V (hB, VGPRs) or back; SKIP:
-// K-blocks 0, 1 are the embedded point xs.  Same chunk walk, ring protocol and arithmetic as layer_ob16<> +
-// convert_last16<> (bit-identical results); the ring's bookkeeping is handed over and taken back here.
-template <class M, bool IN_A, bool SKIP, class PipeT>
-__device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_lds, int g, typename M::Block (&hA)[4][8],
-                                                 typename M::Block (&hB)[4][8], const typename M::Block (&xs)[4][2]) {
-  u32x4 A[32], V[32], X[8];
-  static_for<4>([&](auto t_) {
-    constexpr int t = decltype(t_)::value;
-    static_for<8>([&](auto kb_) {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (IN_A) A[8 * t + kb] = __builtin_bit_cast(u32x4, hA[t][kb].v);
-      else V[8 * t + kb] = __builtin_bit_cast(u32x4, hB[t][kb].v);
-    });
-    static_for<2>([&](auto kb_) { X[2 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, xs[t][decltype(kb_)::value].v); });
-  });
-  hidden_asm_run<M, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
-  static_for<4>([&](auto t_) {
-    constexpr int t = decltype(t_)::value;
-    static_for<8>([&](auto kb_) {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (IN_A) hB[t][kb].v = __builtin_bit_cast(typename M::AFrag, V[8 * t + kb]);
-      else hA[t][kb].v = __builtin_bit_cast(typename M::AFrag, A[8 * t + kb]);
-    });
-  });
-}
-#endif
-
+// This file is compiled twice: as itself, and with -DNS_OB16_TU_T5 as a second translation unit that holds only the
+// five-tile production kernels (the two units build in parallel; each is minutes of register allocation).
+namespace nsob16 {
 struct Nerf16Args {
   const char* stream;
   const float* bias;
@@ -91,15 +33,84 @@ struct Nerf16Args {
   int N;
   float* raw;
 };
+// the five-tile production kernel (PROD, 80 samples per wave): defined in the NS_OB16_TU_T5 unit
+int launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t stream);
+}  // namespace nsob16
+
+namespace {
+
+// diagnostic switch read per launch (tests compare the two paths in one process): "1" selects the generic kernel
+inline bool ns_env_flag(const char* name) {
+  const char* v = std::getenv(name);
+  return v && v[0] == '1';
+}
+
+using namespace nsmlp;
+
+#ifndef NS_NERF16_T
+#define NS_NERF16_T 4
+#endif
+#ifndef NS_NERF16_RELOAD_ONCE
+#define NS_NERF16_RELOAD_ONCE 1   // 1: stashed embeddings come back from LDS once per layer, not once per sub-block
+#endif
+#ifndef NS_NERF16_WAVES
+#define NS_NERF16_WAVES 4
+#endif
+#ifndef NS_OB16_PROD_T
+#define NS_OB16_PROD_T 0          // 16-sample tiles per wave in the production kernel: 4, 5, or 0 = chosen per launch
+#endif
+#ifndef NS_OB16_ASM
+#define NS_OB16_ASM 1             // 1: the W = 256 hidden layers run the hand-scheduled streams of ns_ob16_asm.inc (tools/gen_ob16_asm.py)
+#endif
+constexpr int kT = NS_NERF16_T;          // 16-sample tiles per wave
+constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of activations + accumulators per wave
+                                         // (8 waves x T = 2, two per SIMD in 256 registers each: measured slower, DESIGN.md section 6)
+
+#if NS_OB16_ASM
+}  // namespace
+#ifndef NS_OB16_ASM_INC
+#define NS_OB16_ASM_INC "ns_ob16_asm.inc"
+#endif
+#include NS_OB16_ASM_INC
+namespace {
+// One W = 256 hidden layer (ReLU) as a generated asm statement: set A (hA, AGPRs) -> set V (hB, VGPRs) or back; SKIP:
+// K-blocks 0, 1 are the embedded point xs.  Same chunk walk, ring protocol and arithmetic as layer_ob16<> +
+// convert_last16<> (bit-identical results); the ring's bookkeeping is handed over and taken back here.
+template <class M, int T, bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_lds, int g, typename M::Block (&hA)[T][8],
+                                                 typename M::Block (&hB)[T][8], const typename M::Block (&xs)[T][2]) {
+  u32x4 A[8 * T], V[8 * T], X[2 * T];
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (IN_A) A[8 * t + kb] = __builtin_bit_cast(u32x4, hA[t][kb].v);
+      else V[8 * t + kb] = __builtin_bit_cast(u32x4, hB[t][kb].v);
+    });
+    static_for<2>([&](auto kb_) { X[2 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, xs[t][decltype(kb_)::value].v); });
+  });
+  hidden_asm_run<M, T, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value;
+      if constexpr (IN_A) hB[t][kb].v = __builtin_bit_cast(typename M::AFrag, V[8 * t + kb]);
+      else hA[t][kb].v = __builtin_bit_cast(typename M::AFrag, A[8 * t + kb]);
+    });
+  });
+}
+#endif
+
+using nsob16::Nerf16Args;
 
 // PROD: the production network (8 x 256, skips = [4], view directions: experiments/run.py) as straight-line code whose
 // seven hidden layers are the generated asm statements -- no loop over layers, so the activation sets stay in the registers
 // the statements pin them to; every other network takes the generic, compiler-scheduled path.
-template <class M, int NKB, bool EMBEDDED, bool PROD = false>   // NKB = W / 32 K-blocks of a hidden layer
+template <class M, int NKB, bool EMBEDDED, bool PROD = false, int TT = kT>   // NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
 nerf_mlp_ob16_kernel(Nerf16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int T = kT, NWAVES = kWaves, NSB = 2 * NKB;   // 16-row output sub-blocks of a hidden layer
+  constexpr int T = TT, NWAVES = kWaves, NSB = 2 * NKB;   // 16-row output sub-blocks of a hidden layer
   using Block = typename M::Block;
   using PipeT = Pipe<M, NWAVES, 0, kOb16Depth, kOb16Ahead>;
   const int lane = threadIdx.x & 63;
@@ -306,15 +317,15 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     int l = 1;
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE
     if constexpr (PROD) {
-      static_assert(NKB == 8 && T == 4 && NWAVES == 4, "the generated streams are W = 256, four tiles, four waves");
-      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
-      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 2
-      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 3
-      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 4
+      static_assert(NKB == 8 && (T == 4 || T == 5) && NWAVES == 4, "the generated streams are W = 256, four or five tiles, four waves");
+      hidden_layer_asm<M, T, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
+      hidden_layer_asm<M, T, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 2
+      hidden_layer_asm<M, T, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 3
+      hidden_layer_asm<M, T, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 4
       load_xs();
-      hidden_layer_asm<M, true, true>(ring, bias, g, hA, hB, xs); bias += NSB * 16;     // 5: cat[x, h]
-      hidden_layer_asm<M, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 6
-      hidden_layer_asm<M, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
+      hidden_layer_asm<M, T, true, true>(ring, bias, g, hA, hB, xs); bias += NSB * 16;     // 5: cat[x, h]
+      hidden_layer_asm<M, T, false, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;   // 6
+      hidden_layer_asm<M, T, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
       l = 8;
     }
 #endif
@@ -406,19 +417,19 @@ int ob16_program_slabs(int W, int D, uint32_t skip_mask, int use_viewdirs) {
   return n;
 }
 
-template <class M, int NKB, bool EMB, bool PROD = false>
+template <class M, int NKB, bool EMB, bool PROD = false, int TT = kT>
 int launch(Nerf16Args& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
-                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * kT * 3 * 1024 +
-                     static_cast<size_t>(kWaves) * 10 * (kT > 4 ? 512 : 256);   // ring | bias | embedding stash | input staging
+                     ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * TT * 3 * 1024 +
+                     static_cast<size_t>(kWaves) * 10 * (TT > 4 ? 512 : 256);   // ring | bias | embedding stash | input staging
   if (lds > 160 * 1024) {
     ns::set_error("ns_nerf_forward: %zu bytes of LDS needed (too deep a network for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
   }
-  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB, PROD>;
+  auto kern = nerf_mlp_ob16_kernel<M, NKB, EMB, PROD, TT>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.S + 15) / 16;
-  const int64_t n_groups = (n_tiles + kWaves * kT - 1) / (kWaves * kT);
+  const int64_t n_groups = (n_tiles + kWaves * TT - 1) / (kWaves * TT);
   int cus = ns::cu_count();
   if (cus <= 0) cus = 256;
   const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
@@ -427,17 +438,37 @@ int launch(Nerf16Args& a, hipStream_t stream) {
   return NS_OK;
 }
 
+#ifndef NS_OB16_TU_T5
 template <class M, bool EMB>
 int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE && NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
-  if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC"))
-    return launch<M, 8, EMB, true>(a, stream);   // the production network: hand-scheduled hidden layers
+  if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC")) {
+    // the production network: hand-scheduled hidden layers, four or five 16-sample tiles per wave.  Five tiles read 20 %
+    // fewer weight fragments and refill bytes per sample (-1.15 % per frame, measured); the persistent grid runs
+    // ceil(groups / CUs) rounds of 256 (320) samples per workgroup, so the choice is made per launch on the rounds'
+    // total: a 32768-ray x 64 chunk is exactly 32 rounds of four tiles but 25.6 -> 26 of five.
+    int cus = ns::cu_count();
+    if (cus <= 0) cus = 256;
+    auto rounds = [&](int64_t per_group) { const int64_t g = (a.S + per_group - 1) / per_group; return (g + cus - 1) / cus; };
+    const double t4 = static_cast<double>(rounds(kWaves * 4 * 16)) * 4.0, t5 = static_cast<double>(rounds(kWaves * 5 * 16)) * 5.0 * 0.9885;
+    int tiles = NS_OB16_PROD_T ? NS_OB16_PROD_T : (t5 < t4 ? 5 : 4);
+    if (const char* v = std::getenv("NS_OB16_TILES")) tiles = (v[0] == '5') ? 5 : 4;   // diagnostic override
+    if (tiles == 5) return nsob16::launch_prod_t5(M::kDtype, EMB, a, stream);
+    return launch<M, 8, EMB, true, 4>(a, stream);
+  }
 #endif
   return net->width == 256 ? launch<M, 8, EMB>(a, stream) : launch<M, 4, EMB>(a, stream);
 }
+#endif
 
 }  // namespace
 
+#ifdef NS_OB16_TU_T5
+int nsob16::launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t stream) {
+  if (dtype == Mma16BF16::kDtype) return embedded ? launch<Mma16BF16, 8, true, true, 5>(a, stream) : launch<Mma16BF16, 8, false, true, 5>(a, stream);
+  return embedded ? launch<Mma16F16, 8, true, true, 5>(a, stream) : launch<Mma16F16, 8, false, true, 5>(a, stream);
+}
+#else
 int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
                        float* raw_dev, hipStream_t stream);
@@ -463,10 +494,11 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
   const bool emb = x90_dev != nullptr;
 #ifdef NS_OB16_VARIANT_BUILD   // tools/build_asm_variant.sh: only the kernel under test is instantiated (a 20 s build)
   if (net->dtype == NS_DTYPE_BF16 && !emb && net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs)
-    return launch<Mma16BF16, 8, false, true>(a, stream);
+    return launch<Mma16BF16, 8, false, true, (NS_OB16_PROD_T ? NS_OB16_PROD_T : 4)>(a, stream);
   return NS_E_UNSUPPORTED;
 #endif
   if (net->dtype == NS_DTYPE_BF16) return emb ? dispatch_m<Mma16BF16, true>(net, a, stream) : dispatch_m<Mma16BF16, false>(net, a, stream);
   if (net->dtype == NS_DTYPE_F16) return emb ? dispatch_m<Mma16F16, true>(net, a, stream) : dispatch_m<Mma16F16, false>(net, a, stream);
   return NS_E_UNSUPPORTED;
 }
+#endif  // NS_OB16_TU_T5

@@ -50,7 +50,7 @@ __device__ __forceinline__ void hidden_layer_asm_x3(PipeT& ring, const float* bi
       X[k] = __builtin_bit_cast(u32x4, xs[t][kb].hi); X[k + 1] = __builtin_bit_cast(u32x4, xs[t][kb].lo);
     });
   });
-  hidden_asm_run<Mma16F16x3, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
+  hidden_asm_run<Mma16F16x3, 4, IN_A, SKIP>(ring, bias_lds, g, A, V, X);
   static_for<2>([&](auto t_) {
     constexpr int t = decltype(t_)::value;
     static_for<8>([&](auto kb_) {

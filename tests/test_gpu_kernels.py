@@ -310,11 +310,19 @@ def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_m
         ref = ops.nerf_forward(packed, pts, view)
         torch.cuda.synchronize()
         monkeypatch.delenv("NS_OB16_GENERIC")
-        for _ in range(2):      # twice: the ring phase at the start of a launch does not depend on the previous one
-            got = ops.nerf_forward(packed, pts, view)
-            torch.cuda.synchronize()
-            assert torch.isfinite(got).all()
-            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, R, N, (got - ref).abs().max().item())
+        # the 16-bit production kernel exists with four and with five tiles per wave (chosen per launch; NS_OB16_TILES forces
+        # one): a sample's arithmetic does not depend on the tile it rides in, so both must give the same bits
+        for tiles in (("4", "5", None) if dtype != "f16x3" else (None,)):
+            if tiles is None:
+                monkeypatch.delenv("NS_OB16_TILES", raising=False)
+            else:
+                monkeypatch.setenv("NS_OB16_TILES", tiles)
+            for _ in range(2):      # twice: the ring phase at the start of a launch does not depend on the previous one
+                got = ops.nerf_forward(packed, pts, view)
+                torch.cuda.synchronize()
+                assert torch.isfinite(got).all()
+                assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, tiles, R, N, (got - ref).abs().max().item())
+        monkeypatch.delenv("NS_OB16_TILES", raising=False)
 
 
 @pytest.mark.parametrize("D,W,skip", [(2, 128, -1), (3, 256, 0), (5, 128, 3), (6, 256, 4), (7, 128, 1), (8, 256, -1), (9, 256, 4)])

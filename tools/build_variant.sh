@@ -12,6 +12,7 @@ pids=()
 for f in ns_core.cpp ns_render.cpp; do /opt/rocm/bin/hipcc $flags -x hip -c $src/$f -o $bld/${f%.*}.o & pids+=($!); done
 for f in ns_rays ns_composite ns_pack ns_nerf_mlp ns_depthnet ns_train; do /opt/rocm/bin/hipcc $flags -c $src/$f.hip -o $bld/$f.o & pids+=($!); done
 for f in ns_nerf_mlp_ob16 ns_nerf_mlp_x3 ns_depthnet_ob16; do /opt/rocm/bin/hipcc $flags -mllvm -amdgpu-mfma-vgpr-form -c $src/$f.hip -o $bld/$f.o & pids+=($!); done
+/opt/rocm/bin/hipcc $flags -mllvm -amdgpu-mfma-vgpr-form -DNS_OB16_TU_T5 -c $src/ns_nerf_mlp_ob16.hip -o $bld/ns_nerf_mlp_ob16_t5.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $bld/*.o -o $root/gpurun_ab_$name.so
 echo built $root/gpurun_ab_$name.so

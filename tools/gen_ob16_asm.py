@@ -36,6 +36,41 @@ VALU_WRITE_TO_XDL = 2     # VALU (incl. v_accvgpr_write) write -> MFMA operand r
 XDL_READC_TO_WRITE = 3    # MFMA C read -> another instruction overwrites the register
 
 
+# Conservative clock model on top of the wait-state rules.  The compiler's rules count issue slots; behind a back-to-back
+# MFMA stream execution can lag issue, and an s_nop is the cheapest slot there is.  So the emitter and the checker also
+# keep a clock: an MFMA holds the issue port 8 cycles and the matrix pipe 16, it starts when the pipe is free and may
+# issue while at most one other MFMA is waiting for the pipe; its result is readable XDL_RESULT_MARGIN cycles after it
+# leaves the pipe.  Anything else issues in 4 cycles, s_nop k in k + 1 (a pad is only trusted for one cycle per count).
+MFMA_ISSUE, MFMA_PIPE, OTHER_ISSUE, XDL_RESULT_MARGIN = 8, 16, 4, 16
+
+
+class Clock:
+    def __init__(self):
+        self.t = 0                       # issue clock
+        self.pipe_free = 0               # when the matrix pipe takes the next MFMA
+        self.prev_start = 0              # execution start of the previous MFMA
+        self.ready = {}                  # register -> cycle its MFMA result can be read
+
+    def issue(self, ins):
+        """advance over one instruction; returns the cycle at which it issues"""
+        if ins.kind == "mfma":
+            t0 = max(self.t, self.prev_start)          # issues once the previous MFMA has entered the pipe
+            start = max(t0 + MFMA_ISSUE, self.pipe_free)
+            self.prev_start = start
+            self.pipe_free = start + MFMA_PIPE
+            for r in ins.writes:
+                self.ready[r] = start + MFMA_PIPE + XDL_RESULT_MARGIN
+            self.t = t0 + MFMA_ISSUE
+            return t0
+        t0 = self.t
+        self.t += ins.ws if ins.kind == "nop" else OTHER_ISSUE
+        return t0
+
+    def need(self, regs):
+        """cycles still missing before `regs` (MFMA results) may be touched by a non-MFMA instruction issued now"""
+        return max([self.ready.get(r, 0) - self.t for r in regs] + [0])
+
+
 def R(f, base, n=1):
     return (f, base, n)
 
@@ -95,10 +130,12 @@ class Emitter:
         self.valu_write = {}             # reg -> position after the VALU that wrote it
         self.xdl_cread = {}              # reg -> position after the MFMA that read it as C
         self.lgkm = []                   # outstanding LDS reads (sets of dst regs), in issue order
+        self.clock = Clock()
 
     def _push(self, i):
         self.ins.append(i)
         self.pos += i.ws
+        self.clock.issue(i)
 
     def nop(self, n):                    # n wait states
         while n > 0:
@@ -150,6 +187,7 @@ class Emitter:
         self.wait_lds(rd | wr)
         n = self._need(self.xdl_write, rd | wr, XDL_WRITE_TO_OTHER)
         n = max(n, self._need(self.xdl_cread, wr, XDL_READC_TO_WRITE))
+        n = max(n, self.clock.need(rd | wr))            # the clock model, one cycle per pad count
         self.nop(n)
         self._push(Ins(text, kind, reads=reads, writes=writes))
         return wr
@@ -170,10 +208,11 @@ class Emitter:
     def salu(self, text):
         self._push(Ins(text, "salu"))
 
-    def dma(self, offset):
+    def dma(self, offset, voff=None):
         if OPT.no_dma:
             return
-        self._other(f"global_load_lds_dwordx4 {fmt(VOFF)}, %[sbase]" + (f" offset:{offset}" if offset else ""), "dma", (VOFF,), ())
+        voff = voff or VOFF
+        self._other(f"global_load_lds_dwordx4 {fmt(voff)}, %[sbase]" + (f" offset:{offset}" if offset else ""), "dma", (voff,), ())
 
     def drain_lds(self):
         if self.lgkm:
@@ -186,7 +225,12 @@ def check(ins):
     pos = 0
     xw, vw, xc = {}, {}, {}
     fifo = []
+    clk = Clock()
     for i in ins:
+        if i.kind in ("valu", "lds", "dma"):
+            assert clk.need(i.reads | i.writes) == 0, f"clock model: MFMA result not written back yet: {i.text}"
+        clk.issue(i)
+
         rd_all = i.reads | i.creads
         if i.kind == "wait" and "lgkmcnt" in i.text:
             left = int(i.text.split("lgkmcnt(")[1].split(")")[0])
@@ -233,7 +277,7 @@ def issue_cycles(ins):
     return c
 
 
-def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
+def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
     """One hidden layer, ReLU: set A -> set V (in_a) or set V -> set A; skip: K-blocks 0, 1 are the embedded point.
 
     A chunk step is  [wait] M0 <G0> M1 <G1> M2 <G2> M3 <G3>  (M = the four tiles' MFMAs of one A fragment).  What rides in
@@ -241,12 +285,14 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
     three-stage pipeline so that no VALU instruction directly follows the one it depends on (v_cvt_pk in G2, v_pk_max_i16
     in the NEXT step's G0, v_accvgpr_write in that step's G2); slab bookkeeping (vmcnt + barrier in G0 of a slab's first
     step, its four LDS-DMA pieces in G3 of steps 0..3, scalar updates after them), the next sub-block's bias in G3."""
+    m = m or Map4
+    T, ACC, FR, BIAS, TMP, VOFF, XS = m.T, m.ACC, m.FR, m.BIAS, m.TMP, m.VOFF, m.XS     # (shadow the four-tile globals)
     nkb = nkb_h + (2 if skip else 0)
     total = nsb * nkb
     assert total % SLAB == 0 and total % DEPTH == 0
     slabs = total // SLAB
-    IN = SETA if in_a else SETV
-    OUT = SETV if in_a else SETA
+    IN = m.SETA if in_a else m.SETV
+    OUT = m.SETV if in_a else m.SETA
     cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
     e = Emitter(dt)
     e.salu("s_mov_b32 %[keep], m0")
@@ -281,8 +327,11 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
             dword = piece_regs(s, piece)[2]
             e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,))
 
-    pps = (2 * T + nkb - 1) // nkb       # conversion pieces per chunk step (1 for the hidden layers)
-    assert pps == 1
+    # one piece per chunk step in the main pipeline; a five-tile wave has ten pieces per sub-block: with eight steps the
+    # last two go through gap 3 one after the other (cvt / max / accw at steps 1 / 2 / 3 and 4 / 5 / 6, scratch m.TMP3)
+    n_main = min(2 * T, nkb)
+    extras = list(range(n_main, 2 * T))
+    assert len(extras) <= 2 and (not extras or T == 5)
     max_q, accw_q = [], []               # pieces whose v_pk_max / v_accvgpr_write is due
     pending_salu = []
     for p in range(total):
@@ -319,16 +368,28 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
         g_max() if OPT.swap_g01 else g_read()
         mm(2)
         # ---- G2
-        if sb > 0 and kc < 2 * T and not OPT.no_conv:
+        if sb > 0 and kc < n_main and not OPT.no_conv:
             item = (sb - 1, kc, TMP[kc & 1])
             op_cvt(*item)
             max_q.append(item)
         if accw_q:
             op_accw(*accw_q.pop(0))
         mm(3)
-        # ---- G3
+        if T == 5:
+            # ---- G3 of a five-tile step: the two extra pieces
+            if sb > 0 and not OPT.no_conv:
+                for n, x in enumerate(extras):
+                    stage = kc - (1 + 3 * n)
+                    if stage == 0:
+                        op_cvt(sb - 1, x, m.TMP3)
+                    elif stage == 1:
+                        op_max(sb - 1, x, m.TMP3)
+                    elif stage == 2:
+                        op_accw(sb - 1, x, m.TMP3)
+            mm(4)
+        # ---- last gap
         if c in OPT.dma_steps:
-            e.dma(OPT.dma_steps.index(c) * 1024)
+            e.dma(OPT.dma_steps.index(c) * 1024, VOFF)
             if c == OPT.dma_steps[-1]:
                 pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
                                 "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
@@ -349,15 +410,158 @@ def gen_layer(dt, in_a, skip, nsb=16, nkb_h=8):
             op_accw(*it)
         s = nsb - 1
         scratch = [R('v', ACC((s & 1) ^ 1, 0)[1] + i) for i in range(2 * T)]
-        for piece in range(2 * T):
-            op_cvt(s, piece, scratch[piece])
-        for piece in range(2 * T):
-            op_max(s, piece, scratch[piece])
-        for piece in range(2 * T):
-            op_accw(s, piece, scratch[piece])
+        for t0 in range(0, T, 2):        # two tiles at a time, the tile whose last MFMA is oldest first
+            pcs = [t + T * J for t in (t0, t0 + 1) if t < T for J in (0, 1)]
+            for piece in pcs:
+                op_cvt(s, piece, scratch[piece])
+            for piece in pcs:
+                op_max(s, piece, scratch[piece])
+            for piece in pcs:
+                op_accw(s, piece, scratch[piece])
     e.drain_lds()
     e.salu("s_mov_b32 m0, %[keep]")
     e.nop(VALU_WRITE_TO_XDL)             # our VALU / accvgpr writes ahead of whatever MFMA the compiler issues next
+    if not (OPT.no_wait or OPT.no_lds):
+        check(e.ins)
+    return e, slabs
+
+
+class Map5:
+    """register map of the five-tile wave (80 samples): 160 + 160 activation registers, 40 accumulators"""
+    T = 5
+    @staticmethod
+    def ACC(par, t): return R('v', 20 * par + 4 * t, 4)
+    @staticmethod
+    def FR(i): return R('v', 40 + 4 * (i % DEPTH), 4)
+    BIAS = R('v', 56, 4)
+    TMP = [R('v', 60), R('v', 62)]
+    TMP3 = R('v', 63)
+    VOFF = R('v', 61)
+    @staticmethod
+    def XS(t, kb): return R('a', 160 + 8 * t + 4 * kb, 4)
+    @staticmethod
+    def SETA(t, kb): return R('a', 32 * t + 4 * kb, 4)
+    @staticmethod
+    def SETV(t, kb): return R('v', 96 + 32 * t + 4 * kb, 4)
+    CLOBBER = list(range(0, 40)) + list(range(56, 64))
+
+
+class Map4:
+    T = 4
+    ACC, FR, XS, SETA, SETV = staticmethod(ACC), staticmethod(FR), staticmethod(XS), staticmethod(SETA), staticmethod(SETV)
+    BIAS, TMP, VOFF = BIAS, TMP, VOFF
+    CLOBBER = list(range(0, 32)) + list(range(48, 56))
+
+
+def gen_layer_q(dt, in_a, skip, m, nsb=16, nkb_h=8):
+    """gen_layer() for any tile count (register map m): the conversion is a queue of VALU micro-ops, stage-interleaved in
+    pairs of dwords (cvt, cvt, max, max[, accw, accw]) so that dependent instructions are two gaps apart, one per MFMA gap."""
+    TT = m.T
+    nkb = nkb_h + (2 if skip else 0)
+    total = nsb * nkb
+    assert total % SLAB == 0 and total % DEPTH == 0
+    slabs = total // SLAB
+    IN = m.SETA if in_a else m.SETV
+    OUT = m.SETV if in_a else m.SETA
+    cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+    e = Emitter(dt)
+    e.salu("s_mov_b32 %[keep], m0")
+    e.lds_read(m.BIAS, "%[bias]", 0)
+
+    def dma_setup():
+        e.valu(f"v_lshl_add_u32 {fmt(m.VOFF)}, %[islab], 14, %[loff]", (), (m.VOFF,))
+        e.salu("s_add_u32 m0, %[dsto], %[ldsw]")
+
+    def dma(offset):
+        if not OPT.no_dma:
+            e._other(f"global_load_lds_dwordx4 {fmt(m.VOFF)}, %[sbase]" + (f" offset:{offset}" if offset else ""), "dma", (m.VOFF,), ())
+
+    dma_setup()
+    e.nop(VALU_WRITE_TO_XDL)
+
+    def piece_ops(s, pieces, tmps):
+        """micro-ops of up to two dwords (pieces) of finished sub-block s, stage by stage"""
+        stages = [[], [], []]
+        for piece, tmp in zip(pieces, tmps):
+            t, J = piece % TT, piece // TT
+            a = m.ACC(s & 1, t)
+            lo, hi = R('v', a[1] + 2 * J), R('v', a[1] + 2 * J + 1)
+            dst = OUT(t, s >> 1)
+            dword = R(dst[0], dst[1] + 2 * (s & 1) + J)
+            stages[0].append(lambda lo=lo, hi=hi, tmp=tmp: e.valu(f"{cvt} {fmt(tmp)}, {fmt(lo)}, {fmt(hi)}", (lo, hi), (tmp,)))
+            if in_a:
+                stages[1].append(lambda dword=dword, tmp=tmp: e.valu(f"v_pk_max_i16 {fmt(dword)}, {fmt(tmp)}, 0", (tmp,), (dword,)))
+            else:
+                stages[1].append(lambda tmp=tmp: e.valu(f"v_pk_max_i16 {fmt(tmp)}, {fmt(tmp)}, 0", (tmp,), (tmp,)))
+                stages[2].append(lambda dword=dword, tmp=tmp: e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,)))
+        return [op for st in stages for op in st]
+
+    conv_q = []
+    pending_salu = []
+
+    def conv(n=1):
+        for _ in range(n):
+            if conv_q and not OPT.no_conv:
+                conv_q.pop(0)()
+
+    for p in range(total):
+        sb, kc = divmod(p, nkb)
+        par = sb & 1
+        c = p % SLAB
+        frag = m.FR(p)
+
+        def operand(t):
+            if skip:
+                return m.XS(t, kc) if kc < 2 else IN(t, kc - 2)
+            return IN(t, kc)
+
+        # this step's share of the conversion queue, spread over its gaps (G1 carries the fragment read; a sub-block's
+        # first two gaps stay free): an even pace matters -- the same micro-ops packed into the first steps of a sub-block
+        # cost 4 % of the kernel (measured), the issue port is only just not the bottleneck
+        quota = -(-len(conv_q) // (nkb - kc)) if conv_q else 0
+        cands = [g for g in ([2, 0] + list(range(3, TT))) if g < TT and not (kc == 0 and g < 2)]
+        share = {g: 0 for g in range(TT)}
+        for i in range(quota):
+            share[cands[i % len(cands)]] += 1
+        for t in range(TT):
+            e.mfma(m.ACC(par, t), frag, operand(t), m.BIAS if kc == 0 else m.ACC(par, t))
+            if t == 0 and c == 0 and not OPT.no_barrier:
+                e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
+                e.salu("s_barrier")
+            if t == 1:
+                q = p + DEPTH - 1
+                e.lds_read(m.FR(q), f"%[rb{(q // SLAB) % RING}]", (q % SLAB) * 1024)
+            conv(share[t])
+            if t == TT - 1:
+                if c in OPT.dma_steps:
+                    dma(OPT.dma_steps.index(c) * 1024)
+                    if c == OPT.dma_steps[-1]:
+                        pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
+                                        "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
+                                        "s_and_b32 %[dsto], %[dsto], 0xc000"]
+                elif pending_salu:
+                    e.salu(pending_salu.pop(0))
+                elif c == SLAB - 1 and p + 1 < total:
+                    dma_setup()
+                if kc == min(3, nkb - 1) and sb + 1 < nsb:
+                    e.lds_read(m.BIAS, "%[bias]", 64 * (sb + 1))
+        if kc == nkb - 1 and sb + 1 < nsb:
+            assert not conv_q or OPT.no_conv, f"conversion queue did not drain within one sub-block ({len(conv_q)} left)"
+            for i in range(0, 2 * TT, 2):
+                conv_q.extend(piece_ops(sb, [i, i + 1], m.TMP))
+    assert not pending_salu
+    if not OPT.no_conv:
+        while conv_q:
+            conv_q.pop(0)()
+        s = nsb - 1
+        scratch = [R('v', m.ACC((s & 1) ^ 1, 0)[1] + i) for i in range(2 * TT)]
+        for t0 in range(0, TT, 2):       # two tiles at a time, the tile whose last MFMA is oldest first
+            pcs = [t + TT * J for t in (t0, t0 + 1) if t < TT for J in (0, 1)]
+            for op in piece_ops(s, pcs, [scratch[q] for q in pcs]):
+                op()
+    e.drain_lds()
+    e.salu("s_mov_b32 m0, %[keep]")
+    e.nop(VALU_WRITE_TO_XDL)
     if not (OPT.no_wait or OPT.no_lds):
         check(e.ins)
     return e, slabs
@@ -512,37 +716,39 @@ def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
     return e, slabs
 
 
-def cpp_function(name, dt, in_a, skip, e, slabs):
+def cpp_function(name, dt, in_a, skip, e, slabs, mp=None):
+    mp = mp or Map4
+    nt = mp.T
     m = {"bf16": "Mma16BF16", "f16": "Mma16F16", "f16x3": "Mma16F16x3"}[dt]
     text = "\\n\\t\"\n      \"".join(i.text for i in e.ins)
     outs, ins = [], []
-    for t in range(T):
+    for t in range(nt):
         for kb in range(8):
             k = 8 * t + kb
             if in_a:
-                outs.append(f'"={{{fmt(SETV(t, kb))}}}"(V[{k}])')
-                ins.append(f'"{{{fmt(SETA(t, kb))}}}"(A[{k}])')
+                outs.append(f'"=&{{{fmt(mp.SETV(t, kb))}}}"(V[{k}])')   # early clobber: written while inputs are still read
+                ins.append(f'"{{{fmt(mp.SETA(t, kb))}}}"(A[{k}])')
             else:
-                outs.append(f'"={{{fmt(SETA(t, kb))}}}"(A[{k}])')
-                ins.append(f'"{{{fmt(SETV(t, kb))}}}"(V[{k}])')
+                outs.append(f'"=&{{{fmt(mp.SETA(t, kb))}}}"(A[{k}])')
+                ins.append(f'"{{{fmt(mp.SETV(t, kb))}}}"(V[{k}])')
     for i in range(DEPTH):
-        outs.append(f'"+{{{fmt(FR(i))}}}"(F[{i}])')
+        outs.append(f'"+{{{fmt(mp.FR(i))}}}"(F[{i}])')
     outs += ['[islab] "+s"(islab)', '[dsto] "+s"(dsto)', '[keep] "=&s"(keep)']
     if skip:
-        for t in range(T):
+        for t in range(nt):
             for kb in range(2):
-                ins.append(f'"{{{fmt(XS(t, kb))}}}"(X[{2 * t + kb}])')
+                ins.append(f'"{{{fmt(mp.XS(t, kb))}}}"(X[{2 * t + kb}])')
     ins += ['[rb0] "v"(rb0)', '[rb1] "v"(rb1)', '[rb2] "v"(rb2)', '[rb3] "v"(rb3)', '[bias] "v"(bias)', '[loff] "v"(loff)',
             '[sbase] "s"(sbase)', '[nsl] "s"(nsl)', '[ldsw] "s"(ldsw)']
-    clob = ['"memory"', '"scc"', '"vcc"'] + [f'"v{i}"' for i in list(range(0, 32)) + list(range(48, 56))]
+    clob = ['"memory"', '"scc"', '"vcc"'] + [f'"v{i}"' for i in mp.CLOBBER]
     n_mfma = sum(i.kind == "mfma" for i in e.ins)
     cyc = issue_cycles(e.ins)
     return f"""
 // {name}: {len(e.ins)} instructions, {n_mfma} MFMAs, {slabs} slabs; issue-port estimate {cyc} cycles = {cyc / slabs:.0f} per slab
 // (matrix pipe: {16 * n_mfma / slabs:.0f}); s_nop {sum(i.kind == 'nop' for i in e.ins)}, s_waitcnt {sum(i.kind == 'wait' for i in e.ins)}
-template <> struct HiddenAsm<{m}, {'true' if in_a else 'false'}, {'true' if skip else 'false'}> {{
+template <> struct HiddenAsm<{m}, {nt}, {'true' if in_a else 'false'}, {'true' if skip else 'false'}> {{
   static constexpr int kSlabs = {slabs};
-  static __device__ __forceinline__ void run(u32x4 (&A)[32], u32x4 (&V)[32], const u32x4 (&X)[8], u32x4 (&F)[4],
+  static __device__ __forceinline__ void run(u32x4 (&A)[{8 * nt}], u32x4 (&V)[{8 * nt}], const u32x4 (&X)[{2 * nt}], u32x4 (&F)[4],
                                              uint32_t rb0, uint32_t rb1, uint32_t rb2, uint32_t rb3, uint32_t bias, uint32_t loff,
                                              uint64_t sbase, uint32_t nsl, uint32_t ldsw, uint32_t& islab, uint32_t& dsto) {{
     uint32_t keep;
@@ -564,7 +770,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct Mma16BF16;
 struct Mma16F16;
 struct Mma16F16x3;
-template <class M, bool IN_A, bool SKIP> struct HiddenAsm;
+template <class M, int NT, bool IN_A, bool SKIP> struct HiddenAsm;   // NT: tiles of 8 K-block tuples per activation set
 """
 
 
@@ -572,11 +778,11 @@ FOOTER = """
 // Hands the weight ring's bookkeeping to one generated layer statement and takes it back: set A (a[0:127]) -> set V
 // (v[128:255]) or back; X = the skip layer's embedded point.  Same chunk walk, ring protocol and arithmetic as the
 // compiled layer_ob16<> / layer_ob16x3<> + convert_last16*<>, so results are bit-identical.
-template <class M, bool IN_A, bool SKIP, class PipeT>
-__device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[32], u32x4 (&V)[32], const u32x4 (&X)[8]) {
+template <class M, int NT, bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[8 * NT], u32x4 (&V)[8 * NT], const u32x4 (&X)[2 * NT]) {
   static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
                 "the generated streams assume the default ring");
-  using Gen = HiddenAsm<M, IN_A, SKIP>;
+  using Gen = HiddenAsm<M, NT, IN_A, SKIP>;
   u32x4 F[4];
   static_for<4>([&](auto i_) { F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
   const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
@@ -611,6 +817,9 @@ def main():
         ap.add_argument("--exp-" + k.replace("_", "-"), dest=k, action="store_true")
     ap.add_argument("--dma-steps", default="0,2,4,6")
     ap.add_argument("--swap-g01", action="store_true")
+    ap.add_argument("--no-tiles5", dest="tiles5", action="store_false", help="leave out the five-tile streams")
+    ap.add_argument("--queue5", action="store_true", help="five-tile streams from the generic queue layout")
+    ap.add_argument("--queue4", action="store_true", help="four-tile streams from the generic queue layout (gen_layer_q)")
     a = ap.parse_args()
     OPT.dma_steps = tuple(int(x) for x in a.dma_steps.split(","))
     assert len(OPT.dma_steps) == 4 and OPT.dma_steps[-1] <= 9
@@ -621,13 +830,21 @@ def main():
     for dt in ("bf16", "f16"):
         for in_a in (True, False):
             for skip in (False, True):
-                e, slabs = gen_layer(dt, in_a, skip)
+                e, slabs = gen_layer_q(dt, in_a, skip, Map4) if a.queue4 else gen_layer(dt, in_a, skip)
                 name = f"{dt} {'A->V' if in_a else 'V->A'}{' skip' if skip else ''}"
                 out.append(cpp_function(name, dt, in_a, skip, e, slabs))
                 print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab, "
                       f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
                 if a.dump and a.dump == f"{dt}_{'AV' if in_a else 'VA'}{'_skip' if skip else ''}":
                     open(a.dump + ".s", "w").write("\n".join(i.text for i in e.ins) + "\n")
+    if a.tiles5:
+        for dt in ("bf16", "f16"):
+            for in_a in (True, False):
+                for skip in (False, True):
+                    e, slabs = gen_layer_q(dt, in_a, skip, Map5) if a.queue5 else gen_layer(dt, in_a, skip, Map5)
+                    name = f"{dt} five tiles {'A->V' if in_a else 'V->A'}{' skip' if skip else ''}"
+                    out.append(cpp_function(name, dt, in_a, skip, e, slabs, Map5))
+                    print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 1280)", file=sys.stderr)
     for in_a in (True, False):
         for skip in (False, True):
             e, slabs = gen_layer_x3(in_a, skip)
