@@ -71,6 +71,18 @@ def _launch_ranks(n: int, port: int):
     return procs
 
 
+def kernel_sources_sha256():
+    """identity of the kernel sources (csrc/*): ties profiles/*_traffic_*.json to the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nerf_sampling_amd", "csrc", "*.*"))):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without an outer launcher: start N fresh rank processes (one per GPU, RCCL rendezvous
     on 127.0.0.1) and relay rank 0's JSON line.  The parent never touches the GPU (it has not even imported torch), so
@@ -556,11 +568,19 @@ def main():
                               fine.D, fine.W, 4)
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (PMC counters cannot
     # be read from inside the process); only quoted for the exact workload and build they were collected on
-    tpath = os.path.join(ROOT, "profiles", "r03b_traffic_nerf_mlp.json")
+    tpath = os.path.join(ROOT, "profiles", "r03c_traffic_nerf_mlp.json")
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and os.path.exists(tpath)):
-        roofline["traffic"] = json.load(open(tpath))["hbm_bytes_per_launch"]
-        roofline["traffic_source"] = "profiles/r03b_traffic_nerf_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, not live)"
+        rec = json.load(open(tpath))
+        # the record names the kernel sources it was measured on: a build from other sources gets traffic = null, not a
+        # stale number (tools/profile_round.sh rewrites the record)
+        if rec.get("kernel_sources_sha256") == kernel_sources_sha256():
+            roofline["traffic"] = rec["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = ("profiles/r03c_traffic_nerf_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate "
+                                          "passes on this build's kernel sources; not live)")
+        else:
+            roofline["traffic"] = None
+            roofline["traffic_source"] = "profiles/r03c_traffic_nerf_mlp.json was measured on other kernel sources: not quoted"
 
     if rank == 0:
         rays = H * W * args.steps

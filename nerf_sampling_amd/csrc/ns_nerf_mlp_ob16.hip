@@ -230,15 +230,19 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         });
       });
       asm volatile("" ::: "memory");   // ... and only then the stash writes below (the compiler cannot tell the two LDS regions apart)
-      // One view direction for the whole wave (its 64 consecutive samples lie on one ray whenever N is a multiple of 64,
-      // the headline case): embed it once instead of once per tile.  Compared by VALUE, wave-uniformly; a NaN compares
-      // unequal and takes the per-tile path.
-      bool same_view = a.use_viewdirs != 0;
+      // A view direction is embedded once per RUN of tiles that share it (a wave's consecutive samples lie on one ray when
+      // N is a multiple of 64 and the wave has four tiles, on at most two when it has five): tile t reuses the previous
+      // tile's embedding when its direction compares equal BY VALUE, wave-uniformly; a NaN compares unequal and is embedded.
+      bool new_view[T];
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
-        if constexpr (t > 0) same_view = same_view && V[t][0] == V[0][0] && V[t][1] == V[0][1] && V[t][2] == V[0][2];
+        if constexpr (t == 0) {
+          new_view[0] = true;
+        } else {
+          const bool same = V[t][0] == V[t - 1][0] && V[t][1] == V[t - 1][1] && V[t][2] == V[t - 1][2];
+          new_view[t] = __builtin_amdgcn_ballot_w64(same) != ~0ull;
+        }
       });
-      same_view = __builtin_amdgcn_ballot_w64(same_view) == ~0ull;
       Block ve0[1];
 #ifdef NS_EXP_NOEMBED      // timing ablation: no positional encoding (results are wrong)
       static_for<T>([&](auto t_) {
@@ -248,9 +252,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         xe[t][0] = M::from_f32(x8); xe[t][1] = xe[t][0];
         stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, xe[t][0]);
       });
-      if (false)
 #endif
-      if (same_view) embed3_16<M, false, 4, 1>(ve0, V[0][0], V[0][1], V[0][2], g);
 #ifndef NS_EXP_NOEMBED
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
@@ -259,13 +261,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]);
         if (a.use_viewdirs) {
           ok = ok && finite(V[t][0]) && finite(V[t][1]) && finite(V[t][2]);
-          if (same_view) {
-            stash_put(t, 2, ve0[0]);
-          } else {
-            Block ve[1];
-            embed3_16<M, false, 4, 1>(ve, V[t][0], V[t][1], V[t][2], g);
-            stash_put(t, 2, ve[0]);
-          }
+          if (new_view[t]) embed3_16<M, false, 4, 1>(ve0, V[t][0], V[t][1], V[t][2], g);   // (wave-uniform branch)
+          stash_put(t, 2, ve0[0]);
         }
         if (!ok) bad |= 1u << t;
       });

@@ -24,3 +24,26 @@ cd $root
 python tools/bench_train_step.py bf16 | tail -n 1 > gpurun_out/$tag/train_step_eager_unprofiled.json
 python tools/bench_train_step.py bf16 --graph | tail -n 1 > gpurun_out/$tag/train_step_graph_unprofiled.json
 python tools/pmc_summary.py gpurun_out/$tag | tee gpurun_out/$tag/summary.txt
+# the HBM-traffic record bench.py quotes in `roofline.traffic`, tied to the kernel sources it was measured on
+python - "$tag" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+tag = sys.argv[1]
+m = json.load(open(f"gpurun_out/{tag}/per_launch_means.json"))
+rec = {"workload": "800x800, 64 samples/ray, one launch per frame (fitted scene), bf16",
+       "kernel_sources_sha256": bench.kernel_sources_sha256(),
+       "note": "separate --pmc passes (pmc_fetch / pmc_write counter_collection.csv of the same run, every launch a full frame); "
+               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streaming-read bytes); WRITE_SIZE = 655.36 MB = "
+               "exactly R*N*16 B of raw. Algorithmic bytes: 164 MB z + 23 MB rays + 655 MB raw = 0.84 GB."}
+for k, name in (("nerf_mlp_ob16_kernel", None), ("depthnet_ob16_kernel", "depthnet_ob16_kernel")):
+    d = {"FETCH_SIZE_KB": m[k]["FETCH_SIZE"], "WRITE_SIZE_KB": m[k]["WRITE_SIZE"],
+         "hbm_bytes_per_launch": int(round((2 * m[k]["FETCH_SIZE"] + m[k]["WRITE_SIZE"]) * 1024))}
+    if name:
+        rec[name] = d
+    else:
+        rec.update(d)
+        rec["kernel"] = "nerf_mlp_ob16_kernel (production program, the launch the headline bench times)"
+json.dump(rec, open(f"gpurun_out/{tag}/traffic_nerf_mlp.json", "w"), indent=1)
+print("traffic record:", rec["hbm_bytes_per_launch"], "B per launch, sources", rec["kernel_sources_sha256"][:16])
+PY
