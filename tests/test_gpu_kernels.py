@@ -325,6 +325,40 @@ def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_m
         monkeypatch.delenv("NS_OB16_TILES", raising=False)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3"])
+def test_hand_scheduled_layers_other_input_forms(ops, gpu_modules, dtype, monkeypatch):
+    """The same bit-for-bit comparison for the other two input forms of the production kernels: rays (o, d, z) with the
+    points formed in-kernel -- what the frame renderer launches -- and the pre-embedded [M, 90] rows of NeRF.forward
+    (their own kernel instantiations, four and five tiles)."""
+    m = gpu_modules("lego_synth")
+    packed = m["fine"].packed(dtype)
+    gen = torch.Generator().manual_seed(9)
+    R, N = 1300, 64
+    o = (torch.randn(R, 3, generator=gen) * 0.5).cuda()
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
+    z = (torch.rand(R, N, generator=gen) * 4 + 2).sort(dim=-1).values.cuda()
+    view = d.clone()
+    pts = (o[:, None] + d[:, None] * z[..., None]).cpu()
+    x90 = torch.cat([O.posenc(pts.reshape(-1, 3), 10), O.posenc(view.cpu()[:, None].expand(pts.shape).reshape(-1, 3), 4)], -1).cuda()
+
+    def both():
+        return ops.nerf_forward_rays(packed, o, d, z, view), ops.nerf_forward_embedded(packed, x90)
+
+    monkeypatch.setenv("NS_OB16_GENERIC", "1")
+    ref = both()
+    torch.cuda.synchronize()
+    monkeypatch.delenv("NS_OB16_GENERIC")
+    for tiles in (("4", "5") if dtype != "f16x3" else (None,)):
+        if tiles is not None:
+            monkeypatch.setenv("NS_OB16_TILES", tiles)
+        got = both()
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.isfinite(a).all()
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (dtype, tiles, (a - b).abs().max().item())
+    monkeypatch.delenv("NS_OB16_TILES", raising=False)
+
+
 @pytest.mark.parametrize("D,W,skip", [(2, 128, -1), (3, 256, 0), (5, 128, 3), (6, 256, 4), (7, 128, 1), (8, 256, -1), (9, 256, 4)])
 def test_nerf_mlp_shapes_16bit_vs_fp32(ops, D, W, skip):
     """Program logic of the 16x16x32 kernel (two layers per trip + odd tail, skip at any depth or none, both widths,
