@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Generator of nerf_sampling_amd/csrc/ns_ob16_asm.inc: hand-scheduled gfx950 instruction streams for the hidden layers
-of the 16x16x32 MLP engine (layer_ob16<> in ns_mlp_engine.h is the compiler-scheduled statement of the same layer).
+of the 16x16x32 MLP engine (layer_ob16<> / layer_ob16x3<> in ns_mlp_engine.h are the compiler-scheduled statements of the
+same layers).
 
 Why: a lone wave per SIMD issues in order, and a v_mfma_f32_16x16x32 holds the vector issue port for 8 of its 16 cycles
 (MI355X_MICROARCH.md, cycle constants), so a chunk step (4 MFMAs = 64 matrix cycles) has room for ~8 single-issue
 instructions -- IF they sit evenly between the MFMAs.  The compiler's schedule bunches the conversions, recycles
 accumulator registers as fragment-read targets (s_nop pads) and waits on lgkmcnt in front of most MFMA groups; the
 kernel spends 91 cycles per chunk step instead of 64.  This generator emits the same arithmetic (same MFMA order per
-accumulator: results are bit-identical to layer_ob16<>) as one asm statement per layer with a fixed register map:
+accumulator: results are bit-identical to the compiled layers) as one asm statement per layer with a fixed register map.
+Four-tile wave (64 samples; Map4):
 
   v[0:31]    accumulators  acc[parity][tile] = v[16*parity + 4*tile : +3]     (clobbered)
   v[32:47]   A fragments   f[i] = v[32 + 4 i : +3], chunk p lives in f[p % 4]  (in/out: the ring's read-ahead)
@@ -16,10 +18,20 @@ accumulator: results are bit-identical to layer_ob16<>) as one asm statement per
   a[0:127]   activation set A, hA[tile][kb] = a[32*tile + 4*kb : +3]
   v[128:255] activation set V, hB[tile][kb] = v[128 + 32*tile + 4*kb : +3]
 
+Five-tile wave (80 samples; Map5): accumulators v[0:39], fragments v[40:55], bias v[56:59], scratch v[60:63], set A
+a[0:159], the skip layer's point a[160:199], set V v[96:255]; the compiler keeps v[64:95].  The split-operand (f16x3)
+layers use the four-tile map with (hi, lo) tuple pairs per K-block and two tiles (gen_layer_x3).
+
 Layers alternate A -> V (conversion results are written by VALU straight into set V) and V -> A (one extra
-v_accvgpr_write per dword).  Hazards follow the rules the compiler applies to this MFMA on gfx950 (measured from its own
-output, tools/gen_ob16_asm.py --help): D write -> any other access 8 wait states, VALU write -> MFMA read 2, C read ->
-overwrite 3; the emitter inserts s_nop where a rule needs it and an independent checker pass re-verifies the final text.
+v_accvgpr_write per dword).  Outputs are declared early-clobber: they are written while inputs are still being read (a
+plain "=" let the compiler put an address operand inside the output set).  Hazards follow the rules the compiler applies
+to this MFMA on gfx950 (read off its own output): D write -> any other access 8 wait states, VALU write -> MFMA read 2,
+C read -> overwrite 3, plus a conservative clock model (class Clock); the emitter inserts s_nop / counted lgkmcnt where a
+rule needs it and an independent checker pass re-verifies the final text (tests/test_asm_generator.py).
+
+gen_layer() is the layout in use (one dword converted per chunk step, a three-stage pipeline); gen_layer_q() issues the
+same micro-ops from a queue, one per MFMA gap -- measured 2-4 % slower and kept for that A/B
+(--queue4 / --queue5).  --exp-* flags build timing-only ablations (results wrong on purpose).
 """
 import argparse
 import os
@@ -103,7 +115,6 @@ class Opt:
     no_lds = False       # --exp-no-lds: no fragment reads
     no_barrier = False   # --exp-no-barrier
     dma_steps = (0, 2, 4, 6)   # --dma-steps: chunk steps of a slab whose G3 carries one of the four refill pieces
-    swap_g01 = False     # --swap-g01: fragment read in G0, v_pk_max in G1
 
 
 OPT = Opt()
@@ -362,10 +373,10 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
         if c == 0 and not OPT.no_barrier:
             e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
             e.salu("s_barrier")
-        g_read() if OPT.swap_g01 else g_max()
+        g_max()
         mm(1)
         # ---- G1
-        g_max() if OPT.swap_g01 else g_read()
+        g_read()
         mm(2)
         # ---- G2
         if sb > 0 and kc < n_main and not OPT.no_conv:
@@ -816,14 +827,12 @@ def main():
     for k in ("no_wait", "no_dma", "no_conv", "no_lds", "no_barrier"):
         ap.add_argument("--exp-" + k.replace("_", "-"), dest=k, action="store_true")
     ap.add_argument("--dma-steps", default="0,2,4,6")
-    ap.add_argument("--swap-g01", action="store_true")
     ap.add_argument("--no-tiles5", dest="tiles5", action="store_false", help="leave out the five-tile streams")
     ap.add_argument("--queue5", action="store_true", help="five-tile streams from the generic queue layout")
     ap.add_argument("--queue4", action="store_true", help="four-tile streams from the generic queue layout (gen_layer_q)")
     a = ap.parse_args()
     OPT.dma_steps = tuple(int(x) for x in a.dma_steps.split(","))
     assert len(OPT.dma_steps) == 4 and OPT.dma_steps[-1] <= 9
-    OPT.swap_g01 = a.swap_g01
     for k in ("no_wait", "no_dma", "no_conv", "no_lds", "no_barrier"):
         setattr(OPT, k, getattr(a, k))
     out = [HEADER]
