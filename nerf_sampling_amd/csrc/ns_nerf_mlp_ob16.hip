@@ -59,6 +59,14 @@ using namespace nsmlp;
 #ifndef NS_OB16_PROD_T
 #define NS_OB16_PROD_T 0          // 16-sample tiles per wave in the production kernel: 4, 5, or 0 = chosen per launch
 #endif
+#ifndef NS_OB16_PREFETCH_EARLY
+#define NS_OB16_PREFETCH_EARLY 1  // 1: (all-asm production kernel) the next group's inputs are requested before layer 0 instead of
+                                  // after it: with compiled code between two statements the allocator moved the whole
+                                  // activation set through VGPRs and back (264 copies per group pass; -0.7 % per frame)
+#endif
+#ifndef NS_OB16_ASM_ALL
+#define NS_OB16_ASM_ALL 1         // 1: layer 0, the view layer and the rgb head of the production kernel are generated statements too
+#endif
 #ifndef NS_OB16_ASM
 #define NS_OB16_ASM 1             // 1: the W = 256 hidden layers run the hand-scheduled streams of ns_ob16_asm.inc (tools/gen_ob16_asm.py)
 #endif
@@ -98,6 +106,48 @@ __device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_
       else hA[t][kb].v = __builtin_bit_cast(typename M::AFrag, A[8 * t + kb]);
     });
   });
+}
+// the other three layers of the production network as generated statements (NS_OB16_ASM_ALL): layer 0, the view layer with
+// the sigma sub-block, the rgb head
+template <class M, int T, class PipeT>
+__device__ __forceinline__ void layer0_asm(PipeT& ring, const float* bias_lds, int g, const typename M::Block (&xe)[T][2],
+                                           typename M::Block (&hA)[T][8]) {
+  u32x4 X[2 * T], A[8 * T];
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    X[2 * t] = __builtin_bit_cast(u32x4, xe[t][0].v); X[2 * t + 1] = __builtin_bit_cast(u32x4, xe[t][1].v);
+  });
+  layer0_asm_run<M, T>(ring, bias_lds, g, X, A);
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) { hA[t][decltype(kb_)::value].v = __builtin_bit_cast(typename M::AFrag, A[8 * t + decltype(kb_)::value]); });
+  });
+}
+template <class M, int T, class PipeT>
+__device__ __forceinline__ void views_asm(PipeT& ring, const float* bias_lds, int g, const typename M::Block (&hB)[T][8],
+                                          const typename M::Block (&vs)[T], typename M::Block (&hA)[T][8], f32x4a (&last)[T]) {
+  u32x4 V[8 * T], D[T], A[4 * T], ACCO[T];
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<8>([&](auto kb_) { V[8 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, hB[t][decltype(kb_)::value].v); });
+    D[t] = __builtin_bit_cast(u32x4, vs[t].v);
+  });
+  views_asm_run<M, T>(ring, bias_lds, g, V, D, A, ACCO);
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<4>([&](auto kb_) { hA[t][decltype(kb_)::value].v = __builtin_bit_cast(typename M::AFrag, A[4 * t + decltype(kb_)::value]); });
+    last[t] = __builtin_bit_cast(f32x4a, ACCO[t]);
+  });
+}
+template <class M, int T, class PipeT>
+__device__ __forceinline__ void rgb_asm(PipeT& ring, const float* bias_lds, int g, const typename M::Block (&hA)[T][8], f32x4a (&last)[T]) {
+  u32x4 A[4 * T], ACCO[T];
+  static_for<T>([&](auto t_) {
+    constexpr int t = decltype(t_)::value;
+    static_for<4>([&](auto kb_) { A[4 * t + decltype(kb_)::value] = __builtin_bit_cast(u32x4, hA[t][decltype(kb_)::value].v); });
+  });
+  rgb_asm_run<M, T>(ring, bias_lds, g, A, ACCO);
+  static_for<T>([&](auto t_) { last[decltype(t_)::value] = __builtin_bit_cast(f32x4a, ACCO[decltype(t_)::value]); });
 }
 #endif
 
@@ -307,10 +357,20 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
 #endif
 
     // layer 0: x -> hA
-    layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16;
+#if NS_OB16_ASM && NS_OB16_ASM_ALL
+    if constexpr (PROD) {
+#if NS_OB16_PREFETCH_EARLY
+      prefetch(grp + gridDim.x);
+#endif
+      layer0_asm<M, T>(ring, bias, g, xe, hA); bias += NSB * 16;
+    } else
+#endif
+    { layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16; }
     // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
     // have been consumed (they fed the embeddings above)
-    prefetch(grp + gridDim.x);
+#ifndef NS_EXP_NOPREFETCH
+    if constexpr (!(PROD && NS_OB16_ASM && NS_OB16_ASM_ALL && NS_OB16_PREFETCH_EARLY)) prefetch(grp + gridDim.x);
+#endif
     int l = 1;
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE
     if constexpr (PROD) {
@@ -381,9 +441,16 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         constexpr int kb = decltype(kb_)::value;
         if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
       };
+#if NS_OB16_ASM && NS_OB16_ASM_ALL
+      (void)in_Bv;
+      views_asm<M, T>(ring, bias, g, hB, vs, hA, last); bias += (NSB / 2 + 1) * 16;
+      static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
+      rgb_asm<M, T>(ring, bias, g, hA, last);
+#else
       layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2 + 1) * 16;
       static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
       layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hB, last, in_A);
+#endif
     } else {
     layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });

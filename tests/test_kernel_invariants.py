@@ -98,7 +98,7 @@ def test_nerf16_kernels_use_no_scratch_and_no_full_dma_wait(nerf16_isa):
 
 def test_production_kernel_is_straight_line_hand_scheduled_code(nerf16_isa):
     """The production program (8 x 256, skips = [4]): every MFMA of a group pass appears exactly once (no loop over layers:
-    4 180 per 64 samples), and between the seven generated layer statements the compiler moves no
+    4 180 per 64 samples), and between the ten generated layer statements the compiler moves no
     activation register (the statements pin the two activation sets to a[0:127] / v[128:255]; a copy there would be 128
     v_accvgpr / v_mov instructions per layer)."""
     dis, _ = nerf16_isa
@@ -107,18 +107,23 @@ def test_production_kernel_is_straight_line_hand_scheduled_code(nerf16_isa):
     ins = [i.split("//")[0].strip() for i in next(iter(fns.values()))]
     assert sum("v_mfma_f32_16x16x32_bf16" in i for i in ins) == 4180
     # a generated statement opens with its first bias read into v[48:51]
+    # ten statements: layer 0, seven hidden layers, the view layer, the rgb head
     starts = [n for n, i in enumerate(ins) if re.match(r"ds_read_b128 v\[48:51\], v\d+$", i)]
-    assert len(starts) == 7, starts
-    for a, b in zip(starts, starts[1:]):
+    assert len(starts) == 10, starts
+    mfmas = []
+    for a, b in zip(starts, starts[1:] + [len(ins)]):
         seg = ins[a:b]
-        n_mfma = sum("v_mfma" in i for i in seg)
-        assert n_mfma in (512, 640)
+        if b == len(ins):                # the last statement ends where it restores M0
+            seg = seg[:next(n for n, i in enumerate(seg) if i.startswith("s_mov_b32 m0,")) + 1]
+        mfmas.append(sum("v_mfma" in i for i in seg))
         copies = sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg)
-        assert copies <= 8, (a, b, copies)
-        # what the statements themselves need: one v_accvgpr_write per output dword in the V -> A layers, none in A -> V
-        assert sum(i.startswith("v_accvgpr_write") for i in seg) in (0, 128)
+        assert copies <= 12, (a, b, copies)
+        # what the statements themselves need: one v_accvgpr_write per dword written to set A, none in the A -> V layers
+        w = sum(i.startswith("v_accvgpr_write") for i in seg)
+        assert min(abs(w - k) for k in (0, 64, 128)) <= 8, (a, b, w)
         # hazard pads are the exception in the hand-written stream (the compiled layers carry ~0.2 s_nop per MFMA)
         assert sum(i.startswith("s_nop") for i in seg) <= 12
+    assert mfmas == [128, 512, 512, 512, 512, 640, 512, 512, 324, 16], mfmas
 
 
 def test_five_tile_production_kernel_keeps_scratch_out_of_the_layers():
@@ -143,15 +148,16 @@ def test_five_tile_production_kernel_keeps_scratch_out_of_the_layers():
         ins = [i.split("//")[0].strip() for i in raw]
         assert sum("v_mfma_f32_16x16x32" in i for i in ins) == 5225, name
         starts = [n for n, i in enumerate(ins) if re.match(r"ds_read_b128 v\[56:59\], v\d+$", i)]
-        assert len(starts) == 7, (name, starts)
+        assert len(starts) == 10, (name, starts)
         last_end = next(n for n, i in enumerate(ins[starts[-1]:], starts[-1]) if i.startswith("s_mov_b32 m0,"))   # a statement restores M0 last
         for n, i in enumerate(ins):
             if i.startswith("scratch_"):
                 assert n < starts[0] or n > last_end, (name, n, i)
         for a, b in zip(starts, starts[1:]):
             seg = ins[a:b]
-            assert sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg) <= 8
-            assert sum(i.startswith("v_accvgpr_write") for i in seg) in (0, 160)
+            assert sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg) <= 24   # (a full set is 160)
+            w = sum(i.startswith("v_accvgpr_write") for i in seg)      # a statement's own AGPR writes (+ a few strays)
+            assert min(abs(w - k) for k in (0, 80, 160)) <= 8, w
 
 
 def _check_mlp_kernels(dis, notes, name_part, n_expected, mfma_pat, min_mfma):

@@ -225,6 +225,11 @@ class Emitter:
         voff = voff or VOFF
         self._other(f"global_load_lds_dwordx4 {fmt(voff)}, %[sbase]" + (f" offset:{offset}" if offset else ""), "dma", (voff,), ())
 
+    def settle(self, regs):
+        """pads until MFMA results in `regs` can be read by whatever follows the statement"""
+        rs = set().union(*[regs_of(r) for r in regs])
+        self.nop(max(self._need(self.xdl_write, rs, XDL_WRITE_TO_OTHER), self.clock.need(rs)))
+
     def drain_lds(self):
         if self.lgkm:
             self._push(Ins("s_waitcnt lgkmcnt(0)", "wait"))
@@ -578,6 +583,202 @@ def gen_layer_q(dt, in_a, skip, m, nsb=16, nkb_h=8):
     return e, slabs
 
 
+def special_spec(kind, m):
+    """the three layers of the production network that are not W -> W hidden layers (all write set A or only return raw
+    accumulators): layer 0 (embedded point, 64 -> W), the view layer ((h, dirs) -> W/2 with the sigma head as the one
+    extra, LAST sub-block, returned raw) and the rgb head (W/2 -> 3, one sub-block, returned raw)"""
+    if kind == "layer0":
+        return dict(nsb=16, nkb=2, operand=lambda t, kc: m.XS(t, kc), convert=True, convert_last=True, out_acc=False)
+    if kind == "views":
+        return dict(nsb=9, nkb=9, operand=lambda t, kc: m.SETV(t, kc) if kc < 8 else m.XS(t, 0), convert=True, convert_last=False, out_acc=True)
+    if kind == "rgb":
+        return dict(nsb=1, nkb=4, operand=lambda t, kc: m.SETA(t, kc), convert=False, convert_last=False, out_acc=True)
+    raise ValueError(kind)
+
+
+def gen_layer_special(dt, kind, m):
+    """Layer 0, view layer, rgb head as statements (queue layout of gen_layer_q: together they are 9 of the 67 slabs).
+    Their streams are not slab multiples: the chunks are padded to the fragment pipeline depth (pad steps carry no MFMA),
+    the last slab may be short (its refill pieces ride on its first four steps)."""
+    sp = special_spec(kind, m)
+    TT, nsb, nkb = m.T, sp["nsb"], sp["nkb"]
+    real = nsb * nkb
+    total = -(-real // DEPTH) * DEPTH
+    slabs = -(-total // SLAB)
+    cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+    e = Emitter(dt)
+    e.salu("s_mov_b32 %[keep], m0")
+    e.lds_read(m.BIAS, "%[bias]", 0)
+
+    def dma_setup():
+        e.valu(f"v_lshl_add_u32 {fmt(m.VOFF)}, %[islab], 14, %[loff]", (), (m.VOFF,))
+        e.salu("s_add_u32 m0, %[dsto], %[ldsw]")
+
+    dma_setup()
+    e.nop(VALU_WRITE_TO_XDL)
+
+    def piece_ops(s, pieces, tmps):
+        stages = [[], [], []]
+        for piece, tmp in zip(pieces, tmps):
+            t, J = piece % TT, piece // TT
+            a = m.ACC(s & 1, t)
+            lo, hi = R('v', a[1] + 2 * J), R('v', a[1] + 2 * J + 1)
+            dst = m.SETA(t, s >> 1)
+            dword = R(dst[0], dst[1] + 2 * (s & 1) + J)
+            stages[0].append(lambda lo=lo, hi=hi, tmp=tmp: e.valu(f"{cvt} {fmt(tmp)}, {fmt(lo)}, {fmt(hi)}", (lo, hi), (tmp,)))
+            stages[1].append(lambda tmp=tmp: e.valu(f"v_pk_max_i16 {fmt(tmp)}, {fmt(tmp)}, 0", (tmp,), (tmp,)))
+            stages[2].append(lambda dword=dword, tmp=tmp: e.valu(f"v_accvgpr_write_b32 {fmt(dword)}, {fmt(tmp)}", (tmp,), (dword,)))
+        return [op for st in stages for op in st]
+
+    conv_q, pending_salu = [], []
+
+    def conv(n=1):
+        for _ in range(n):
+            if conv_q:
+                conv_q.pop(0)()
+
+    def read_ahead(p):
+        q = p + DEPTH - 1
+        if q < real:
+            e.lds_read(m.FR(q), f"%[rb{(q // SLAB) % RING}]", (q % SLAB) * 1024)
+        elif q >= total:                 # the next statement's first chunks, in the slab after this layer's last
+            e.lds_read(m.FR(q), f"%[rb{slabs % RING}]", (q - total) * 1024)
+
+    for p in range(total):
+        c = p % SLAB
+        slab_len = min(SLAB, total - (p - c))
+        dma_steps = OPT.dma_steps if slab_len > OPT.dma_steps[-1] else (0, 1, 2, 3)
+        last_of_slab = c == slab_len - 1
+
+        def bookkeeping():
+            nonlocal pending_salu
+            if c in dma_steps:
+                e.dma(dma_steps.index(c) * 1024, m.VOFF)
+                if c == dma_steps[-1]:
+                    pending_salu = ["s_add_i32 %[islab], %[islab], 1", "s_cmp_lg_u32 %[islab], %[nsl]",
+                                    "s_cselect_b32 %[islab], %[islab], 0", "s_add_i32 %[dsto], %[dsto], 0x4000",
+                                    "s_and_b32 %[dsto], %[dsto], 0xc000"]
+            elif pending_salu:
+                e.salu(pending_salu.pop(0))
+            if last_of_slab:
+                while pending_salu:
+                    e.salu(pending_salu.pop(0))
+                if p + 1 < total:
+                    dma_setup()
+
+        if p >= real:                    # pad step: no MFMA
+            if c == 0 and not OPT.no_barrier:
+                e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
+                e.salu("s_barrier")
+            read_ahead(p)
+            conv(len(conv_q))
+            bookkeeping()
+            continue
+        sb, kc = divmod(p, nkb)
+        par = sb & 1
+        frag = m.FR(p)
+        quota = -(-len(conv_q) // (nkb - kc)) if conv_q else 0
+        cands = [g for g in ([2, 0] + list(range(3, TT))) if g < TT and not (kc == 0 and g < 2)]
+        share = {g: 0 for g in range(TT)}
+        for i in range(quota):
+            share[cands[i % len(cands)]] += 1
+        for t in range(TT):
+            e.mfma(m.ACC(par, t), frag, sp["operand"](t, kc), m.BIAS if kc == 0 else m.ACC(par, t))
+            if t == 0 and c == 0 and not OPT.no_barrier:
+                e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
+                e.salu("s_barrier")
+            if t == 1:
+                read_ahead(p)
+            conv(share[t])
+            if t == TT - 1:
+                bookkeeping()
+                if kc == min(3, nkb - 1) and sb + 1 < nsb:
+                    e.lds_read(m.BIAS, "%[bias]", 64 * (sb + 1))
+        if kc == nkb - 1 and sp["convert"] and (sb + 1 < nsb):
+            assert not conv_q, f"conversion queue did not drain within one sub-block ({len(conv_q)} left)"
+            if sb + 1 < nsb or sp["convert_last"]:
+                for i in range(0, 2 * TT, 2):
+                    conv_q.extend(piece_ops(sb, [i, i + 1], m.TMP))
+    assert not pending_salu
+    while conv_q:
+        conv_q.pop(0)()
+    if sp["convert_last"]:
+        s_ = nsb - 1
+        scratch = [R('v', m.ACC((s_ & 1) ^ 1, 0)[1] + i) for i in range(2 * TT)]
+        for t0 in range(0, TT, 2):
+            pcs = [t + TT * J for t in (t0, t0 + 1) if t < TT for J in (0, 1)]
+            for op in piece_ops(s_, pcs, [scratch[q] for q in pcs]):
+                op()
+    if sp["out_acc"]:
+        e.settle([m.ACC((nsb - 1) & 1, t) for t in range(TT)])
+    e.drain_lds()
+    e.salu("s_mov_b32 m0, %[keep]")
+    e.nop(VALU_WRITE_TO_XDL)
+    check(e.ins)
+    return e, slabs
+
+
+def cpp_special(dt, kind, e, slabs, mp):
+    """struct SpecialAsm<M, NT, KIND>: KIND 0 = layer 0 (X -> set A), 1 = view layer (set V, D -> set A K-blocks 0..3, raw
+    accumulators of the sigma sub-block), 2 = rgb head (set A K-blocks 0..3 -> raw accumulators)"""
+    nt = mp.T
+    mname = {"bf16": "Mma16BF16", "f16": "Mma16F16"}[dt]
+    kid = {"layer0": 0, "views": 1, "rgb": 2}[kind]
+    text = "\\n\\t\"\n      \"".join(i.text for i in e.ins)
+    outs, ins, params = [], [], []
+    acc_out = kind in ("views", "rgb")
+    if kind == "layer0":
+        params = [f"const u32x4 (&X)[{2 * nt}]", f"u32x4 (&A)[{8 * nt}]"]
+        for t in range(nt):
+            for kb in range(8):
+                outs.append(f'"=&{{{fmt(mp.SETA(t, kb))}}}"(A[{8 * t + kb}])')
+            for kb in range(2):
+                ins.append(f'"{{{fmt(mp.XS(t, kb))}}}"(X[{2 * t + kb}])')
+    elif kind == "views":
+        params = [f"const u32x4 (&V)[{8 * nt}]", f"const u32x4 (&D)[{nt}]", f"u32x4 (&A)[{4 * nt}]", f"u32x4 (&ACCO)[{nt}]"]
+        for t in range(nt):
+            for kb in range(4):
+                outs.append(f'"=&{{{fmt(mp.SETA(t, kb))}}}"(A[{4 * t + kb}])')
+            for kb in range(8):
+                ins.append(f'"{{{fmt(mp.SETV(t, kb))}}}"(V[{8 * t + kb}])')
+            ins.append(f'"{{{fmt(mp.XS(t, 0))}}}"(D[{t}])')
+    else:
+        params = [f"const u32x4 (&A)[{4 * nt}]", f"u32x4 (&ACCO)[{nt}]"]
+        for t in range(nt):
+            for kb in range(4):
+                ins.append(f'"{{{fmt(mp.SETA(t, kb))}}}"(A[{4 * t + kb}])')
+    clobber = list(mp.CLOBBER)
+    if acc_out:
+        for t in range(nt):
+            r = mp.ACC(0, t)
+            outs.append(f'"=&{{{fmt(r)}}}"(ACCO[{t}])')
+            for i in range(4):
+                clobber.remove(r[1] + i)
+    for i in range(DEPTH):
+        outs.append(f'"+{{{fmt(mp.FR(i))}}}"(F[{i}])')
+    outs += ['[islab] "+s"(islab)', '[dsto] "+s"(dsto)', '[keep] "=&s"(keep)']
+    ins += ['[rb0] "v"(rb0)', '[rb1] "v"(rb1)', '[rb2] "v"(rb2)', '[rb3] "v"(rb3)', '[bias] "v"(bias)', '[loff] "v"(loff)',
+            '[sbase] "s"(sbase)', '[nsl] "s"(nsl)', '[ldsw] "s"(ldsw)']
+    clob = ['"memory"', '"scc"', '"vcc"'] + [f'"v{i}"' for i in clobber]
+    n_mfma = sum(i.kind == "mfma" for i in e.ins)
+    return f"""
+// {dt} {nt} tiles {kind}: {len(e.ins)} instructions, {n_mfma} MFMAs, {slabs} slabs; s_nop {sum(i.kind == 'nop' for i in e.ins)}
+template <> struct SpecialAsm<{mname}, {nt}, {kid}> {{
+  static constexpr int kSlabs = {slabs};
+  static __device__ __forceinline__ void run({', '.join(params)}, u32x4 (&F)[4],
+                                             uint32_t rb0, uint32_t rb1, uint32_t rb2, uint32_t rb3, uint32_t bias, uint32_t loff,
+                                             uint64_t sbase, uint32_t nsl, uint32_t ldsw, uint32_t& islab, uint32_t& dsto) {{
+    uint32_t keep;
+    asm volatile(
+      "{text}"
+      : {', '.join(outs)}
+      : {', '.join(ins)}
+      : {', '.join(clob)});
+  }}
+}};
+"""
+
+
 def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
     """One hidden layer of the split-operand kernel (f16x3: x = hi + lo in fp16, three MFMAs per product term), T = 2
     tiles: layer_ob16x3<> + convert_last16x3<> of ns_mlp_engine.h as one statement.  A sub-block is 2 nkb chunks: chunk
@@ -782,39 +983,83 @@ struct Mma16BF16;
 struct Mma16F16;
 struct Mma16F16x3;
 template <class M, int NT, bool IN_A, bool SKIP> struct HiddenAsm;   // NT: tiles of 8 K-block tuples per activation set
+template <class M, int NT, int KIND> struct SpecialAsm;             // KIND: 0 layer 0, 1 view layer, 2 rgb head
 """
 
 
 FOOTER = """
-// Hands the weight ring's bookkeeping to one generated layer statement and takes it back: set A (a[0:127]) -> set V
-// (v[128:255]) or back; X = the skip layer's embedded point.  Same chunk walk, ring protocol and arithmetic as the
-// compiled layer_ob16<> / layer_ob16x3<> + convert_last16*<>, so results are bit-identical.
-template <class M, int NT, bool IN_A, bool SKIP, class PipeT>
-__device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[8 * NT], u32x4 (&V)[8 * NT], const u32x4 (&X)[2 * NT]) {
+// Hands the weight ring's bookkeeping to a generated layer statement and takes it back.  Same chunk walk, ring protocol
+// and arithmetic as the compiled layer_ob16<> / layer_ob16x3<> (+ convert_last16*<>), so results are bit-identical.
+struct AsmRingArgs {
+  u32x4 F[4];
+  uint32_t rb0, rb1, rb2, rb3, bias, loff, nsl, ldsw, islab, dsto;
+  uint64_t sbase;
+};
+template <class PipeT>
+__device__ __forceinline__ void asm_ring_begin(PipeT& ring, const float* bias_lds, int g, AsmRingArgs& r) {
   static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
                 "the generated streams assume the default ring");
-  using Gen = HiddenAsm<M, NT, IN_A, SKIP>;
-  u32x4 F[4];
-  static_for<4>([&](auto i_) { F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
+  static_for<4>([&](auto i_) { r.F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
   const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
-  const uint32_t rb0 = lane16 + ((ring.read_slot + 0) & 3) * kSlabBytes, rb1 = lane16 + ((ring.read_slot + 1) & 3) * kSlabBytes;
-  const uint32_t rb2 = lane16 + ((ring.read_slot + 2) & 3) * kSlabBytes, rb3 = lane16 + ((ring.read_slot + 3) & 3) * kSlabBytes;
-  const uint32_t bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(bias_lds))) + 16u * static_cast<uint32_t>(g);
+  r.rb0 = lane16 + ((ring.read_slot + 0) & 3) * kSlabBytes; r.rb1 = lane16 + ((ring.read_slot + 1) & 3) * kSlabBytes;
+  r.rb2 = lane16 + ((ring.read_slot + 2) & 3) * kSlabBytes; r.rb3 = lane16 + ((ring.read_slot + 3) & 3) * kSlabBytes;
+  r.bias = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(bias_lds))) + 16u * static_cast<uint32_t>(g);
+  r.loff = static_cast<uint32_t>(ring.lane) * 16u;
   const uint64_t base = reinterpret_cast<uint64_t>(ring.stream) + static_cast<uint64_t>(ring.wave) * (4 * kChunkBytes);
   const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
   const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
-  const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
-  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(ring.lds_off + static_cast<uint32_t>(ring.wave) * (4 * kChunkBytes));
-  uint32_t islab = __builtin_amdgcn_readfirstlane(ring.issue_slab);
-  uint32_t dsto = __builtin_amdgcn_readfirstlane(ring.issue_slot * kSlabBytes);
-  Gen::run(A, V, X, F, rb0, rb1, rb2, rb3, bias, static_cast<uint32_t>(ring.lane) * 16u, sbase,
-           __builtin_amdgcn_readfirstlane(ring.n_slabs), ldsw, islab, dsto);
-  ring.issue_slab = islab;
-  ring.issue_slot = dsto / kSlabBytes;
-  ring.read_slot = (ring.read_slot + Gen::kSlabs) & 3;
+  r.sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
+  r.ldsw = __builtin_amdgcn_readfirstlane(ring.lds_off + static_cast<uint32_t>(ring.wave) * (4 * kChunkBytes));
+  r.nsl = __builtin_amdgcn_readfirstlane(ring.n_slabs);
+  r.islab = __builtin_amdgcn_readfirstlane(ring.issue_slab);
+  r.dsto = __builtin_amdgcn_readfirstlane(ring.issue_slot * kSlabBytes);
+}
+template <class AFrag, class PipeT>
+__device__ __forceinline__ void asm_ring_end(PipeT& ring, const AsmRingArgs& r, int slabs) {
+  ring.issue_slab = r.islab;
+  ring.issue_slot = r.dsto / kSlabBytes;
+  ring.read_slot = (ring.read_slot + slabs) & 3;
   ring.nxt = ring.lds_off + ring.read_slot * kSlabBytes + static_cast<uint32_t>(ring.lane) * 16u;
   ring.cur = ring.nxt;
-  static_for<4>([&](auto i_) { ring.f[decltype(i_)::value] = __builtin_bit_cast(typename M::AFrag, F[decltype(i_)::value]); });
+  static_for<4>([&](auto i_) { ring.f[decltype(i_)::value] = __builtin_bit_cast(AFrag, r.F[decltype(i_)::value]); });
+}
+
+// one hidden layer: set A (a[..]) -> set V (v[..]) or back; X = the skip layer's embedded point
+template <class M, int NT, bool IN_A, bool SKIP, class PipeT>
+__device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[8 * NT], u32x4 (&V)[8 * NT], const u32x4 (&X)[2 * NT]) {
+  using Gen = HiddenAsm<M, NT, IN_A, SKIP>;
+  AsmRingArgs r;
+  asm_ring_begin(ring, bias_lds, g, r);
+  Gen::run(A, V, X, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto);
+  asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
+}
+// layer 0: the embedded point X -> set A
+template <class M, int NT, class PipeT>
+__device__ __forceinline__ void layer0_asm_run(PipeT& ring, const float* bias_lds, int g, const u32x4 (&X)[2 * NT], u32x4 (&A)[8 * NT]) {
+  using Gen = SpecialAsm<M, NT, 0>;
+  AsmRingArgs r;
+  asm_ring_begin(ring, bias_lds, g, r);
+  Gen::run(X, A, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto);
+  asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
+}
+// view layer: (set V, embedded direction D) -> K-blocks 0..3 of set A; ACCO = raw accumulators of the last (sigma) sub-block
+template <class M, int NT, class PipeT>
+__device__ __forceinline__ void views_asm_run(PipeT& ring, const float* bias_lds, int g, const u32x4 (&V)[8 * NT], const u32x4 (&D)[NT],
+                                              u32x4 (&A)[4 * NT], u32x4 (&ACCO)[NT]) {
+  using Gen = SpecialAsm<M, NT, 1>;
+  AsmRingArgs r;
+  asm_ring_begin(ring, bias_lds, g, r);
+  Gen::run(V, D, A, ACCO, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto);
+  asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
+}
+// rgb head: K-blocks 0..3 of set A -> raw accumulators
+template <class M, int NT, class PipeT>
+__device__ __forceinline__ void rgb_asm_run(PipeT& ring, const float* bias_lds, int g, const u32x4 (&A)[4 * NT], u32x4 (&ACCO)[NT]) {
+  using Gen = SpecialAsm<M, NT, 2>;
+  AsmRingArgs r;
+  asm_ring_begin(ring, bias_lds, g, r);
+  Gen::run(A, ACCO, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto);
+  asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
 }
 }  // namespace nsmlp
 """
@@ -854,6 +1099,11 @@ def main():
                     name = f"{dt} five tiles {'A->V' if in_a else 'V->A'}{' skip' if skip else ''}"
                     out.append(cpp_function(name, dt, in_a, skip, e, slabs, Map5))
                     print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 1280)", file=sys.stderr)
+    for dt in ("bf16", "f16"):
+        for mp in ((Map4, Map5) if a.tiles5 else (Map4,)):
+            for kind in ("layer0", "views", "rgb"):
+                e, slabs = gen_layer_special(dt, kind, mp)
+                out.append(cpp_special(dt, kind, e, slabs, mp))
     for in_a in (True, False):
         for skip in (False, True):
             e, slabs = gen_layer_x3(in_a, skip)
