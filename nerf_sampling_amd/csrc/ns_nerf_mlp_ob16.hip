@@ -465,7 +465,11 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         const int64_t sidx = sample_of(grp, t, n, valid);
         float4 o4 = make_float4(last[t][0], last[t][1], last[t][2], sigma[t]);
         if ((bad >> t) & 1u) { const float q = __builtin_nanf(""); o4 = make_float4(q, q, q, q); }
+#ifdef NS_EXP_NOSTORE      // timing ablation: raw never leaves the kernel (what would compositing in the epilogue be worth?)
+        if (valid && o4.x == 123456.0f) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
+#else
         if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
+#endif
       });
     }
   }
