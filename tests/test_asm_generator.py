@@ -62,6 +62,44 @@ def test_five_tile_stream_shape(gen, in_a, skip):
     gen.check(e.ins)
 
 
+@pytest.mark.parametrize("tiles", [4, 5])
+def test_special_layer_streams(gen, tiles):
+    """layer 0, the view layer (sigma sub-block returned raw) and the rgb head: streams that are not slab multiples -- pad
+    steps without MFMAs, a short last slab that still gets its four refill pieces and its barrier"""
+    m = gen.Map4 if tiles == 4 else gen.Map5
+    want = {"layer0": (16 * 2, 2, True), "views": (9 * 9, 6, True), "rgb": (1 * 4, 1, False)}
+    for kind, (chunks, slabs_want, converts) in want.items():
+        e, slabs = gen.gen_layer_special("bf16", kind, m)
+        kinds = [i.kind for i in e.ins]
+        assert slabs == slabs_want
+        assert kinds.count("mfma") == tiles * chunks
+        assert kinds.count("dma") == 4 * slabs and sum("s_barrier" in i.text for i in e.ins) == slabs
+        n_cvt = sum(i.text.startswith("v_cvt_pk") for i in e.ins)
+        n_conv_sb = {"layer0": 16, "views": 8, "rgb": 0}[kind]          # converted sub-blocks (the view layer's last one is raw)
+        assert n_cvt == 2 * tiles * n_conv_sb and (n_cvt > 0) == converts
+        # every conversion lands in set A (an AGPR write per dword), K-blocks 0..7 (layer 0) or 0..3 (view layer)
+        wr = set().union(*[i.writes for i in e.ins if i.text.startswith("v_accvgpr_write")]) if converts else set()
+        kbs = {(r - 32 * (r // 32)) // 4 for f, r in wr}
+        assert all(f == "a" for f, _ in wr) and kbs == ({0, 1, 2, 3, 4, 5, 6, 7} if kind == "layer0" else ({0, 1, 2, 3} if converts else set()))
+        gen.check(e.ins)
+
+
+@pytest.mark.parametrize("in_a", [True, False])
+@pytest.mark.parametrize("skip", [False, True])
+def test_split_operand_stream_shape(gen, in_a, skip):
+    """f16x3: per K-block a W_hi chunk (x_hi and x_lo of both tiles) and a W_lo chunk (x_hi only): three MFMAs per product
+    term; ten (twelve with the AGPR writes) VALU instructions per converted dword pair"""
+    e, slabs = gen.gen_layer_x3(in_a, skip)
+    nkb = 10 if skip else 8
+    kinds = [i.kind for i in e.ins]
+    assert slabs == 2 * nkb and kinds.count("mfma") == 16 * nkb * 6 and kinds.count("lds") == 16 * 2 * nkb + 16
+    valu = [i.text.split()[0] for i in e.ins if i.kind == "valu"]
+    pairs = 16 * 4                                    # sub-blocks x (two tiles x two dword pairs)
+    assert valu.count("v_cvt_pk_f16_f32") == 2 * pairs and valu.count("v_cmp_ngt_f32_e32") == 2 * pairs
+    assert valu.count("v_sub_f32_e32") == 2 * pairs and valu.count("v_accvgpr_write_b32") == (0 if in_a else 2 * pairs)
+    gen.check(e.ins)
+
+
 def test_checker_rejects_broken_streams(gen):
     e, _ = gen.gen_layer("bf16", True, False)
     ins = list(e.ins)
