@@ -511,14 +511,14 @@ template <class M, bool EMB>
 int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE && NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
   if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC")) {
-    // the production network: hand-scheduled hidden layers, four or five 16-sample tiles per wave.  Five tiles read 20 %
-    // fewer weight fragments and refill bytes per sample (-1.15 % per frame, measured); the persistent grid runs
-    // ceil(groups / CUs) rounds of 256 (320) samples per workgroup, so the choice is made per launch on the rounds'
-    // total: a 32768-ray x 64 chunk is exactly 32 rounds of four tiles but 25.6 -> 26 of five.
+    // the production network: hand-scheduled layers, four or five 16-sample tiles per wave.  Five tiles read 20 % fewer
+    // weight fragments and refill bytes per sample (-2.5 % per frame on the final build, profiles/r03c_ab_tiles_final_build.log);
+    // the persistent grid runs ceil(groups / CUs) rounds of 256 (320) samples per workgroup, so the choice is made per
+    // launch on the rounds' total: a 32768-ray x 64 chunk is exactly 32 rounds of four tiles but 25.6 -> 26 of five.
     int cus = ns::cu_count();
     if (cus <= 0) cus = 256;
     auto rounds = [&](int64_t per_group) { const int64_t g = (a.S + per_group - 1) / per_group; return (g + cus - 1) / cus; };
-    const double t4 = static_cast<double>(rounds(kWaves * 4 * 16)) * 4.0, t5 = static_cast<double>(rounds(kWaves * 5 * 16)) * 5.0 * 0.9885;
+    const double t4 = static_cast<double>(rounds(kWaves * 4 * 16)) * 4.0, t5 = static_cast<double>(rounds(kWaves * 5 * 16)) * 5.0 * 0.975;
     int tiles = NS_OB16_PROD_T ? NS_OB16_PROD_T : (t5 < t4 ? 5 : 4);
     if (const char* v = std::getenv("NS_OB16_TILES")) tiles = (v[0] == '5') ? 5 : 4;   // diagnostic override
     if (tiles == 5) return nsob16::launch_prod_t5(M::kDtype, EMB, a, stream);
