@@ -714,7 +714,8 @@ def gen_layer_special(dt, kind, m):
     e.drain_lds()
     e.salu("s_mov_b32 m0, %[keep]")
     e.nop(VALU_WRITE_TO_XDL)
-    check(e.ins)
+    if not (OPT.no_wait or OPT.no_lds):
+        check(e.ins)
     return e, slabs
 
 
