@@ -279,11 +279,8 @@ class HipAdam(torch.optim.Adam):
         if self._dev_step is not None:
             return
         params = [p for g in self.param_groups for p in g["params"]]
-        steps = {int(self.state[p]["step"].item()) if len(self.state[p]) else 0 for p in params}
-        if len(steps) > 1 or len(self.param_groups) != 1:
-            raise NotImplementedError("the device step counter needs one parameter group and one common step count")
         dev = params[0].device
-        self._host_steps = steps.pop() if steps else 0
+        self._host_steps = self._common_step(params)
         self._dev_step = torch.full((1,), self._host_steps, dtype=torch.int32, device=dev)
         self._dev_lr = torch.full((1,), float(self.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
         self._lr_seen = float(self.param_groups[0]["lr"])
@@ -294,6 +291,38 @@ class HipAdam(torch.optim.Adam):
         self._table_host = [torch.empty((5 * len(params),), dtype=torch.int64, device="cpu").pin_memory() for _ in range(2)]
         self._table_dev = [torch.empty((5 * len(params),), dtype=torch.int64, device=dev) for _ in range(2)]
         self._table_event = None
+
+    def _common_step(self, params) -> int:
+        """The one step count all parameters share ('step' is a tensor in torch's own state, a plain int in older checkpoints)."""
+        def as_int(v):
+            return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+        steps = {as_int(self.state[p]["step"]) if len(self.state[p]) else 0 for p in params}
+        if len(steps) > 1 or len(self.param_groups) != 1:
+            raise NotImplementedError("the device step counter needs one parameter group and one common step count")
+        return steps.pop() if steps else 0
+
+    def load_state_dict(self, state_dict):
+        """torch's loader; in device-step mode the device counter, the host count and the learning-rate scalar are re-seeded
+        from the loaded state (a checkpoint loaded AFTER use_device_step() must not keep the old bias corrections)."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():                       # torch's step() convention: 'step' is a CPU fp32 tensor
+            if "step" in st and not isinstance(st["step"], torch.Tensor):
+                st["step"] = torch.tensor(float(st["step"]))
+        if self._dev_step is not None:
+            params = [p for g in self.param_groups for p in g["params"]]
+            self._host_steps = self._common_step(params)
+            self._dev_step.fill_(self._host_steps)
+            self._lr_seen = None
+            self.sync_device_lr()
+
+    def claim_capture_table(self):
+        """Called once by the (single) captured step of this optimizer: the captured update re-reads row table [1] on every
+        replay, so a second capture from the same optimizer would overwrite the rows the first graph points at."""
+        if getattr(self, "_capture_claimed", False):
+            raise RuntimeError("this HipAdam already backs a captured step: one hipGraph capture per optimizer "
+                               "(build a new optimizer, or reuse the existing GraphedDepthNetStep)")
+        self._capture_claimed = True
 
     def note_replayed_step(self):
         """A captured graph containing step() was replayed once."""

@@ -322,7 +322,7 @@ int ns_pack_nerf_ex(int D, int W, uint32_t skip_mask, int use_viewdirs, int outp
   NS_REQUIRE(out && w && b, "null pointer");
   *out = nullptr;
   const int out_ch = use_viewdirs ? 4 : output_ch;
-  if (!(W == 128 || W == 256) || D < 1 || D > 32 || (D < 32 && (skip_mask >> (D - 1)) != 0) || out_ch < 1 || out_ch > 16 ||
+  if (!(W == 128 || W == 256) || D < 1 || D > 32 || (skip_mask >> (D - 1)) != 0 || out_ch < 1 || out_ch > 16 ||
       !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
     ns::set_error("ns_pack_nerf: unsupported network (W=%d D=%d skips=0x%x output_ch=%d dtype=%d); kernels exist for "
                   "W in {128,256}, D <= 32, skips before the last layer, input_ch 63 (/27), output_ch <= 16", W, D, skip_mask,

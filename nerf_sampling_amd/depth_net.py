@@ -44,6 +44,7 @@ class DepthNet(nn.Module):
         self.cat_layers = nn.Sequential(*cat)
         self.to_depth = nn.Sequential(nn.Linear(cat_hidden_sizes[-1], 1), nn.Sigmoid())
         self._packed = {}
+        self._unpackable = set()      # operand types these weights were found not to fit (reset with the weights: repack())
 
     def calculate_intersection_points(self, rays_o, rays_d):
         _, pts = find_intersection_points_with_sphere(rays_o, rays_d, self.sphere_radius)
@@ -75,11 +76,11 @@ class DepthNet(nn.Module):
         itself if the weights do not fit fp16's range."""
         if dtype is None:
             name, paired = ops.get_compute_dtype(), ops.depthnet_dtype_for()
-            if paired != name:
+            if paired != name and paired not in self._unpackable:
                 try:
                     return self.packed(paired)
                 except NotImplementedError:
-                    pass
+                    self._unpackable.add(paired)      # (e.g. weights beyond fp16's range) do not re-fold / re-pack per call
         else:
             name = dtype
         if name not in self._packed:
@@ -93,11 +94,13 @@ class DepthNet(nn.Module):
 
     def repack(self):
         self._packed = {}
+        self._unpackable = set()
 
     def __getstate__(self):
         # packed device weight streams are caches of the parameters: never pickled / deep-copied
         state = self.__dict__.copy()
         state["_packed"] = {}
+        state["_unpackable"] = set()
         return state
 
     def load_state_dict(self, *a, **k):
@@ -113,7 +116,7 @@ class DepthNet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import depthnet_forward_train
 
-            self._packed = {}  # weights are about to change
+            self.repack()  # weights are about to change
             return depthnet_forward_train(self, rays_o, rays_d)
         return ops.depthnet_forward(self.packed(), rays_o, rays_d, self.near, self.far,
                                     float(self.sphere_radius.reshape(-1)[0]))

@@ -304,7 +304,12 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
         rgb, disp, extras = render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], _defer_host_sync=True, **render_kwargs)
         sink = _last_sink if rgb.is_cuda else None
         if sink is not None:
-            rgb, disp = sink.copy_whole(rgb), sink.copy_whole(disp)
+            # rgb is a device tensor (nerf_utils.py:867 keeps it there); disp already IS this frame's pinned sink buffer
+            # (depth_net_disp_map, filled chunk by chunk on the sink's stream): a host-to-host copy_ of it would run at once,
+            # ahead of the queued device-to-host copies, and snapshot stale data.  consume() reads it after sink.finish().
+            rgb = sink.copy_whole(rgb)
+            if disp.is_cuda:
+                disp = sink.copy_whole(disp)
         if prev is not None:
             consume(*prev)
         prev = (i, rgb, disp, extras, sink)

@@ -315,6 +315,7 @@ class GraphedDepthNetStep:
         self.rays, self.target = batch_rays.clone(), target_s.clone()
         self.opt.zero_grad(set_to_none=True)           # backward inside the capture allocates the grads in the graph's pool
         torch.cuda.synchronize()
+        self.opt.claim_capture_table()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.img_loss, self.dn_loss = self.tr._optimization_step(self.opt, self.kw, self.rays, 1 << 30, self.target,

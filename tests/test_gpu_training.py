@@ -299,7 +299,9 @@ def test_use_batching_and_ray_dump(tmp_path, gpu_modules):
 def test_graphed_step_equals_eager_step(gpu_modules):
     """trainers.GraphedDepthNetStep (forward + backward + Adam as ONE hipGraph replay per step) against
     core_optimization_loop on the same batches: identical losses and bit-identical DepthNet weights and Adam state after
-    six steps (two eager warm-up steps, capture, four replays), and a step counter that checkpoints like torch's."""
+    eight steps -- two eager warm-up steps, the capture, four replays, then a batch of ANOTHER size (the eager fallback after
+    a capture: its update goes through the optimizer's eager row table, the graph's gradient pool is left alone) and a
+    replay again -- and a step counter that checkpoints like torch's.  A second capture from the same optimizer is refused."""
     from nerf_sampling_amd import ops
     from nerf_sampling_amd.autograd import HipAdam
 
@@ -309,7 +311,8 @@ def test_graphed_step_equals_eager_step(gpu_modules):
     _, K = O.blender_intrinsics(H, W)
     o, d, _ = ops.get_rays(H, W, K, O.pose_spherical(20.0, -30.0, 4.0)[:3, :4])
     g = torch.Generator().manual_seed(3)
-    batches = [(torch.randint(0, H * W, (128,), generator=g).cuda(), torch.rand(128, 3, generator=g).cuda()) for _ in range(6)]
+    batches = [(torch.randint(0, H * W, (n,), generator=g).cuda(), torch.rand(n, 3, generator=g).cuda())
+               for n in (128, 128, 128, 128, 128, 128, 96, 128)]
     results = {}
     for mode in ("eager", "graph"):
         m = dict(base)
@@ -330,7 +333,11 @@ def test_graphed_step_equals_eager_step(gpu_modules):
             loss, dn_loss, psnr, _ = step(torch.stack([o[idx], d[idx]], 0), i, tgt)
             losses.append((float(loss), float(dn_loss), float(psnr)))
         if mode == "graph":
-            assert step.graph is not None and step.calls == 6
+            assert step.graph is not None and step.calls == 8
+            with pytest.raises(RuntimeError, match="one hipGraph capture per optimizer"):
+                again = tr.graphed_optimization_loop(opt, kw)
+                again.warmup = 0
+                again(torch.stack([o[batches[0][0]], d[batches[0][0]]], 0), 0, batches[0][1])
         sd = opt.state_dict()
         results[mode] = (losses, [p.detach().clone() for p in m["depth"].parameters()], sd)
     le, pe, sde = results["eager"]
@@ -338,6 +345,37 @@ def test_graphed_step_equals_eager_step(gpu_modules):
     assert le == lg, (le, lg)
     assert all(torch.equal(a, b) for a, b in zip(pe, pg))
     for k in sde["state"]:
-        assert float(sde["state"][k]["step"]) == float(sdg["state"][k]["step"]) == 6.0
+        assert float(sde["state"][k]["step"]) == float(sdg["state"][k]["step"]) == 8.0
         assert torch.equal(sde["state"][k]["exp_avg_sq"], sdg["state"][k]["exp_avg_sq"])
     assert le[-1][1] < le[0][1]                            # and it trains
+
+
+def test_hip_adam_reloads_its_state_in_device_step_mode(gpu_modules):
+    """HipAdam.load_state_dict AFTER use_device_step(): the device step counter (bias corrections), the host count and the
+    learning-rate scalar follow the loaded state, whether the checkpoint stores 'step' as a tensor (torch >= 1.12) or as a
+    plain int (older checkpoints); the next update equals torch.optim.Adam's from the same state."""
+    from nerf_sampling_amd.autograd import HipAdam
+
+    torch.manual_seed(0)
+    for step_as_int in (False, True):
+        w = torch.nn.Parameter(torch.randn(300, device="cuda"))
+        ref_w = torch.nn.Parameter(w.detach().clone())
+        ref = torch.optim.Adam([ref_w], lr=2e-3)
+        grads = [torch.randn(300, device="cuda") for _ in range(4)]
+        for gr in grads[:3]:                               # three steps of torch's Adam make the state to load
+            ref_w.grad = gr.clone()
+            ref.step()
+        sd = ref.state_dict()
+        if step_as_int:
+            for st in sd["state"].values():
+                st["step"] = int(st["step"])
+        opt = HipAdam([w], lr=1e-3)
+        opt.use_device_step()                              # device mode first (trainers.GraphedDepthNetStep does this) ...
+        with torch.no_grad():
+            w.copy_(ref_w)
+        opt.load_state_dict(sd)                            # ... the checkpoint afterwards
+        assert opt._host_steps == 3 and int(opt._dev_step.item()) == 3 and abs(float(opt._dev_lr.item()) - 2e-3) < 1e-9
+        w.grad, ref_w.grad = grads[3].clone(), grads[3].clone()
+        opt.step(); ref.step()
+        assert torch.allclose(w, ref_w, rtol=0, atol=2e-7), float((w - ref_w).abs().max())
+        assert float(opt.state_dict()["state"][0]["step"]) == 4.0

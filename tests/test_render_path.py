@@ -105,6 +105,39 @@ def test_render_only_pipeline_with_reference_checkpoints(tmp_path, gpu_modules):
     assert sd["all_pts"].shape == (2 * H * W * 16, 3) and sd["all_weights"].shape == (2 * H * W * 16,)
 
 
+@pytest.mark.gpu
+def test_render_path_frames_equal_per_frame_render_test(gpu_modules):
+    """render_path's software pipeline (frame i consumed under frame i+1, pooled pinned buffers, deferred host copies) returns
+    per pose exactly what a stand-alone render_test of that pose returns -- rgbs AND disps (the disparity map reaches the host
+    through the frame's sink buffer; round 3 snapshotted it before its device-to-host copies had run)."""
+    from nerf_sampling_amd import nerf_utils, ops
+    from nerf_sampling_amd.run_nerf_helpers import get_embedder
+    from nerf_sampling_amd.synthetic import blender_intrinsics, pose_spherical
+    from nerf_sampling_amd.trainers import DepthNetTrainer
+
+    ops.set_compute_dtype("f32")
+    m = gpu_modules("tiny_synth")
+    tr = DepthNetTrainer(dataset_type="blender", basedir="/tmp", expname="rp", no_batching=True, datadir="", half_res=True,
+                         white_bkgd=True, N_importance=128, use_viewdirs=True, input_dims_embed=3, n_depth_samples=16,
+                         sampling_mode="uniform", distance=0.1)
+    e1, _ = get_embedder(10, 0, 3)
+    e2, _ = get_embedder(4, 0, 3)
+    query = lambda i, v, f: tr.run_network(i, v, f, embed_fn=e1, embeddirs_fn=e2)  # noqa: E731
+    H = W = 48
+    focal, K = blender_intrinsics(H, W)
+    kw = dict(ndc=False, near=2.0, far=6.0, use_viewdirs=True, network_fn=m["coarse"], network_query_fn=query, N_samples=64,
+              trainer=tr, network_fine=m["fine"], depth_network=m["depth"], white_bkgd=True, lindisp=True)
+    poses = torch.stack([pose_spherical(a, -30.0, 4.0) for a in (0.0, 72.0, 144.0, 216.0)])
+    chunk = 1000                                     # several ragged chunks per frame
+    rgbs, disps, _ = nerf_utils.render_path(poses, (H, W, focal), K, chunk, kw, step=0)
+    assert rgbs.shape == (4, H, W, 3) and disps.shape == (4, H, W)
+    for i, c2w in enumerate(poses):
+        rgb, disp, _ = nerf_utils.render_test(H, W, K, chunk=chunk, c2w=c2w[:3, :4], **kw)
+        np.testing.assert_array_equal(rgbs[i], rgb.cpu().numpy())
+        np.testing.assert_array_equal(disps[i], disp.cpu().numpy())
+    assert len({d.tobytes() for d in disps}) == 4    # four different frames, not one buffer seen four times
+
+
 def _cli_root(tmp_path, m, n_test=2):
     """A reference-layout root (dataset/lego, pretrained/nerf|depth_net/lego/...) holding a random 'lego' dataset of 32x32
     files (the yaml has half_res: True) and the modules' weights as 200000.tar checkpoints."""
