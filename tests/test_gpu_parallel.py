@@ -57,21 +57,24 @@ def test_two_ranks_assemble_the_single_process_frame(tmp_path, gpu_modules):
             np.testing.assert_array_equal(got["disp"].reshape(-1), full["disp"].cpu().numpy())
 
 
-def test_bench_self_launches_its_ranks():
-    """`python bench.py --gpus 2` with no outer launcher (how the round-end driver may run it) starts two rank processes
-    itself and labels the line with the world size it really ran on (gloo here: both ranks share the one GPU)."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_self_launches_its_ranks(world):
+    """`python bench.py --gpus N` with no outer launcher (how the round-end driver may run it) starts N rank processes
+    itself and labels the line with the world size it really ran on (gloo here: the ranks share the one GPU).  Four is the
+    most this box rehearses: its process guard allows six processes on the card, the test runner being one of them -- the
+    eight-rank frame assembly is covered on the CPU (tests/test_parallel_gloo.py), RCCL at world > 1 by the driver's run."""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "64",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--size", "64",
                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_world"] == 2 and out["backend"] == "gloo"
+    assert out["n_gpus"] == world and out["rccl_world"] == world and out["backend"] == "gloo"
     assert out["value"] > 0 and out["steps"] == 2 and out["scaling"] == "strong"
