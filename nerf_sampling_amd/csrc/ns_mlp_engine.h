@@ -227,9 +227,6 @@ struct Pipe {
   uint32_t cur;         // this lane's LDS byte address in the open slab (chunk c at +c*1024)
   uint32_t nxt;         // ... and in the following one
   AFrag f[DEPTH];       // fragments of the next DEPTH chunks
-#ifdef NS_EXP_NODMA
-  bool exp_no_dma = false;
-#endif
 
   __device__ static __forceinline__ uint32_t next_slot(uint32_t slot) {
     if constexpr ((RING & (RING - 1)) == 0) return (slot + 1) & (RING - 1);   // one s_and instead of compare + select
@@ -247,9 +244,6 @@ struct Pipe {
     // instruction (address = s[base] + 32-bit lane offset + immediate), the immediate offset stepping through both the
     // global and the LDS address.  Saves a 64-bit VALU add, an M0 write and its wait state per piece.
     if constexpr (LPW * kChunkBytes <= 4096) {
-#ifdef NS_EXP_NODMA
-      if (!exp_no_dma)
-#endif
       {
         const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * (LPW * kChunkBytes);
         const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * (LPW * kChunkBytes);
@@ -286,17 +280,8 @@ struct Pipe {
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
     const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
-#ifdef NS_EXP_NODMA        // timing ablation: the ring is refilled by the prologue only (results are wrong)
-    if (exp_no_dma) {
-      asm volatile("" ::"v"(src + lane_off), "s"(dst));
-    } else {
-#pragma unroll
-      for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
-    }
-#else
 #pragma unroll
     for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
-#endif
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = next_slot(issue_slot);
   }
@@ -318,9 +303,6 @@ struct Pipe {
   template <int I>
   __device__ __forceinline__ void issue_piece_saddr() {
     static_assert(I >= 0 && I < LPW && LPW * kChunkBytes <= 4096, "piece index");
-#ifdef NS_EXP_NODMA
-    if (exp_no_dma) return;
-#endif
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * (LPW * kChunkBytes);
     const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * (LPW * kChunkBytes);
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
@@ -359,11 +341,7 @@ struct Pipe {
   // lgkmcnt(0) every fourth MFMA -- same kernel time (35.4 vs 35.2 ms), so the compiler-visible form stays.
   template <int OFF>
   __device__ __forceinline__ void load(AFrag& dst, uint32_t addr) const {
-#ifdef NS_EXP_NOLDS        // timing ablation: fragments are never re-read (results are wrong)
-    (void)dst; (void)addr;
-#else
     dst = *reinterpret_cast<const AFrag __attribute__((address_space(3)))*>(static_cast<uintptr_t>(addr + OFF));
-#endif
   }
   __device__ static __forceinline__ void wait_frag(AFrag&) {}
 
@@ -372,9 +350,6 @@ struct Pipe {
     issue_slab = 0; issue_slot = 0; read_slot = 0;
     lds_off = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(NS_LDS_PTR(lds_)));
     static_for<AHEAD>([&](auto) { issue(); });    // slabs 0 .. AHEAD-1
-#ifdef NS_EXP_NODMA
-    exp_no_dma = true;
-#endif
     wait_vm<(AHEAD - 1) * LPW>();                 // my pieces of slab 0 have landed ...
     __builtin_amdgcn_s_barrier();                 // ... and everyone else's
     asm volatile("" ::: "memory");
@@ -411,12 +386,8 @@ struct Pipe {
 
   // Open the next slab: its first kFragDepth fragments are already in registers.
   __device__ __forceinline__ void begin_slab() {
-#ifndef NS_EXP_NOWAIT     // NS_EXP_*: timing ablations only (results are wrong)
     wait_vm<(AHEAD - 2) * LPW>();                 // my pieces of the slab AFTER this one have landed
-#endif
-#ifndef NS_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();                 // everyone's; all waves are done with the previous slab
-#endif
     asm volatile("" ::: "memory");
     issue();                                      // refill the slot the previous slab occupied
     cur = lds_off + read_slot * kSlabBytes + lane * 16;
@@ -851,13 +822,7 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
           static_for<PPS>([&](auto i_) {
             constexpr int piece = kc * PPS + decltype(i_)::value;
             if constexpr (piece < PIECES) {
-#ifdef NS_EXP_NOCONV       // timing ablation: finished sub-blocks are not converted (results are wrong)
-              const f32x4a keep = c[par ^ 1][piece % T];
-              auto& ob = out[piece % T][(sb - 1) >> 1].v;      // stays "defined" so that later layers are not folded away
-              asm volatile("" : "+v"(ob) : "v"(keep));
-#else
               convert_piece16<M, ACT, sb - 1, piece / T>(out[piece % T][(sb - 1) >> 1], c[par ^ 1][piece % T]);
-#endif
             }
           });
         }

@@ -7,6 +7,12 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=${NS_VARIANT_SRC:-$root/nerf_sampling_amd/csrc}   # NS_VARIANT_SRC: build the kernels of another checkout (A/B against an older commit)
 bld=/tmp/ns_variant_$name
 mkdir -p $bld
+if [ -n "$NS_ABLATIONS" ]; then   # timing-only NS_EXP_* ablations live in a patch, not in the production sources (tools/ablations/README.md)
+  rm -rf $bld/src && mkdir -p $bld/src/nerf_sampling_amd $bld/src/include
+  cp -r $src $bld/src/nerf_sampling_amd/csrc && cp $root/include/*.h $bld/src/include/
+  (cd $bld/src && patch -p1 < $root/tools/ablations/ns_exp_ablations.patch)
+  src=$bld/src/nerf_sampling_amd/csrc
+fi
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off $*"
 pids=()
 for f in ns_core.cpp ns_render.cpp; do /opt/rocm/bin/hipcc $flags -x hip -c $src/$f -o $bld/${f%.*}.o & pids+=($!); done
