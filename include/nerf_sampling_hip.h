@@ -49,6 +49,12 @@ const char* ns_last_error(void);
 int ns_version(void);
 /* number of compute units of the current device (0 if no device) */
 int ns_device_cu_count(void);
+/* Diagnostic switches of the kernel dispatch (tests compare code paths inside one process; no effect on results):
+ *   "generic_kernels" 0/1 -- 1: the production network (8 x 256, skips = [4]) runs the generic compiler-scheduled kernels
+ *                            instead of the generated instruction streams;
+ *   "prod_tiles" 0/4/5    -- tiles per wave of the 16-bit production kernel, 0 = chosen per launch.
+ * Initial values come from the environment (NS_OB16_GENERIC, NS_OB16_TILES), read once at first use.              */
+int ns_debug_set(const char* name, int value);
 
 /* ---- a1  get_rays + prepare_rays  (run_nerf_helpers.py:187-202, nerf_utils.py:156-188) ----
  * Pixel rows [row0,row1) of an HxW pinhole camera, row-major.  c2w is 12 HOST floats (3x4,
@@ -218,9 +224,26 @@ typedef struct ns_render_args {
    * disp_dev = rgb_dev + 3 writes an interleaved [R,4] shard directly                                  */
   int64_t rgb_stride;
   int64_t disp_stride;
+  /* PSNR guard (optional, NS_MODE_UNIFORM only; NULL = off).  The reference composites the LAST sample of a ray with
+   * dist = 1e10 (sampling_trainer.py:176-180): alpha_last = step(sigma_last), so with 16-bit operands a sigma_last near
+   * zero flips a ray's colour.  With a second handle of the SAME network packed NS_DTYPE_F16X3 (fp32-grade) here, the
+   * last sample of every ray is evaluated a second time through it (R of the R*N samples, ~5 % of the frame) and its
+   * sigma replaces the 16-bit one before compositing.  Pair it with an F16X3 DepthNet handle for fp32-grade depths.  */
+  const ns_weights* nerf_guard;
 } ns_render_args;
 int64_t ns_render_workspace_bytes(int64_t R, int N);
 int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
+/* The same operator as ONE kernel per ray tile (the reference's chain nerf_utils.py:836-865):
+ * rays -> DepthNet -> [sample placement + radiance-field MLP + raw2outputs in one persistent kernel].  Sample depths are
+ * evaluated in-kernel from the DepthNet depth (no z array), raw stays in the CU and is composited in the MLP kernel's
+ * epilogue by the same wave scan ns_raw2outputs runs: rgb / disp (and z / weights / pts when asked for) are BIT-IDENTICAL
+ * to ns_render_rays_depthnet.  Three launches per call (ray generation, DepthNet, the fused kernel); HBM traffic is the
+ * rays, 4 B + 16 B per ray and the weight streams.  Supported (ns_render_fused_supported != 0): mode NS_MODE_UNIFORM,
+ * a bf16 / f16 NeRF handle with view directions, N a power of two in [2, 64]; anything else returns NS_E_UNSUPPORTED and
+ * is served by ns_render_rays_depthnet.  Workspace: ns_render_fused_workspace_bytes(R) bytes, 256-byte aligned.        */
+int ns_render_fused_supported(const ns_weights* nerf, int mode, int N);
+int64_t ns_render_fused_workspace_bytes(int64_t R);
+int ns_render_rays_fused(const ns_render_args* args, void* stream);
 
 /* ---- a11 as one call: sample_as_in_NeRF (nerf_utils.py:497-611) = coarse pass, inverse-CDF importance
  * sampling, sorted merge, fine pass.  Rays explicit or generated from the camera (o_dev == NULL).
@@ -252,6 +275,8 @@ typedef struct ns_hier_args {
   void* ev_mlp_end;
   int64_t rgb_stride; /* as in ns_render_args; 0 = packed */
   int64_t disp_stride;
+  void* ev_coarse_begin; /* optional hipEvent_t pair around the COARSE-pass MLP kernel */
+  void* ev_coarse_end;
 } ns_hier_args;
 int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf);
 int ns_render_rays_hierarchical(const ns_hier_args* args, void* stream);

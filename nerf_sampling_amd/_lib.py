@@ -38,6 +38,7 @@ class RenderArgs(C.Structure):
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("pts_dev", _p),
         ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
         ("rgb_stride", _i64), ("disp_stride", _i64),
+        ("nerf_guard", _p),
     ]
 
 
@@ -55,6 +56,7 @@ class HierArgs(C.Structure):
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("raw_dev", _p),
         ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
         ("rgb_stride", _i64), ("disp_stride", _i64),
+        ("ev_coarse_begin", _p), ("ev_coarse_end", _p),
     ]
 
 
@@ -63,6 +65,7 @@ SIGNATURES = {
     "ns_last_error": (C.c_char_p, []),
     "ns_version": (_i, []),
     "ns_device_cu_count": (_i, []),
+    "ns_debug_set": (_i, [C.c_char_p, _i]),
     "ns_get_rays": (_i, [_i, _i, _f, _f, _f, _f, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
     "ns_sphere_intersect": (_i, [_p, _p, _i64, _f, _p, _p, _p]),
     "ns_solve_quadratic": (_i, [_p, _p, _p, _i64, _p, _p]),
@@ -90,6 +93,9 @@ SIGNATURES = {
     "ns_argmax_gather": (_i, [_p, _p, _p, _i64, _i, _p, _p, _p, _p]),
     "ns_render_workspace_bytes": (_i64, [_i64, _i]),
     "ns_render_rays_depthnet": (_i, [C.POINTER(RenderArgs), _p]),
+    "ns_render_fused_supported": (_i, [_p, _i, _i]),
+    "ns_render_fused_workspace_bytes": (_i64, [_i64]),
+    "ns_render_rays_fused": (_i, [C.POINTER(RenderArgs), _p]),
     "ns_hier_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ns_render_rays_hierarchical": (_i, [C.POINTER(HierArgs), _p]),
     "ns_gemm_strided": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),

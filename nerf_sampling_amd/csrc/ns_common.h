@@ -25,6 +25,13 @@ inline int ew_grid(int64_t n, int block) {
   return static_cast<int>(g);
 }
 
+// diagnostic switches (ns_debug_set; initial values from NS_OB16_GENERIC / NS_OB16_TILES, read once)
+struct DebugFlags {
+  int generic_kernels;   // 1: the production network runs the generic, compiler-scheduled kernels (tests compare the two)
+  int prod_tiles;        // 4 / 5: tiles per wave of the 16-bit production kernel; 0 = chosen per launch
+};
+DebugFlags& debug_flags();
+
 int cu_count();
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 

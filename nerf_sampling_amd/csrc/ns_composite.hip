@@ -59,8 +59,8 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
         if (alphas_out) alphas_out[e] = alpha;
         if (weights_out) weights_out[e] = w;
       }
-      nscomp::composite_finish<SW>(A, white_bkgd, disp);
-      if (cur.live && sub == 0) {
+      nscomp::composite_finish<SW>(A, white_bkgd, disp, sub);
+      if (cur.live && sub == SW - 1) {                     // the group's last lane holds the totals
         const int64_t r = cur.r;
         if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = A.r; p[1] = A.g; p[2] = A.b; }
         if (acc_out) acc_out[r] = A.acc;
@@ -98,8 +98,8 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
       }
     }
     float disp;
-    nscomp::composite_finish<SW>(A, white_bkgd, disp);
-    if (live && sub == 0) {
+    nscomp::composite_finish<SW>(A, white_bkgd, disp, sub);
+    if (live && sub == SW - 1) {
       if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = A.r; p[1] = A.g; p[2] = A.b; }
       if (acc_out) acc_out[r] = A.acc;
       if (depth_out) depth_out[r] = A.depth;
@@ -466,3 +466,21 @@ int ns_argmax_gather(const float* weights_dev, const float* z_dev, const float* 
 }
 
 }  // extern "C"
+
+#include "ns_weights.h"
+namespace {
+__global__ void __launch_bounds__(256)
+patch_sigma_last_kernel(float4* __restrict__ raw, const float4* __restrict__ raw_last, int64_t R, int N) {
+  for (int64_t r = blockIdx.x * (int64_t)256 + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256)
+    raw[r * N + (N - 1)].w = raw_last[r].w;
+}
+}  // namespace
+// sigma of every ray's last sample <- the guard pass's (ns_render_args::nerf_guard; the chain renderer)
+int ns_patch_sigma_last(float* raw_dev, const float* raw_last_dev, int64_t R, int N, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 1 && raw_dev && raw_last_dev, "bad arguments");
+  if (R == 0) return NS_OK;
+  patch_sigma_last_kernel<<<ns::ew_grid(R, 256), 256, 0, ns::as_stream(stream)>>>(
+      reinterpret_cast<float4*>(raw_dev), reinterpret_cast<const float4*>(raw_last_dev), R, N);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}

@@ -1,10 +1,10 @@
-// Per-ray alpha compositing of raw2outputs_kernel (ns_composite.hip), kept as lane-level building blocks.
-// (Round 1 also ran them as an epilogue of the 16-bit NeRF kernel for N == 64 -- a wave's two tiles are one ray --
-// bit-identical and raw never reached HBM, but at one wave per SIMD the ~200 epilogue instructions per ray are
-// exposed: the kernel grew by exactly the 0.25 ms the separate launch costs, so the fusion was not kept.)
+// Per-ray alpha compositing as lane-level building blocks: raw2outputs_kernel (ns_composite.hip) and the epilogue of the
+// one-kernel renderer (ns_nerf_mlp_ob16.hip) both run exactly this code, so they agree bit for bit.
 // raw2alpha + raw2outputs: nerf_utils.py:27-42, sampling_trainer.py:153-230.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 namespace nscomp {
 
@@ -17,6 +17,35 @@ struct RayAccum {
 // ‖d‖ as torch.norm computes it on the CPU (fma chain)
 __device__ __forceinline__ float ray_norm(float dx, float dy, float dz) {
   return sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+}
+
+// ---- wave-level scans on DPP (gfx9 data-parallel primitives: the shifted operand is read by the VALU instruction itself, no
+// LDS round trip; a __shfl is a ds_bpermute with ~100 cycles of latency, and the scan is a dependent chain of them).
+// dpp<CTRL>(old, x): lane i receives x of the lane CTRL selects, or `old` where that lane does not exist / the row is masked.
+constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118, kRowBcast15 = 0x142, kRowBcast31 = 0x143,
+              kWaveShr1 = 0x138;
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp(float old, float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL,
+                                                               ROW_MASK, 0xF, false));
+}
+// Inclusive scan over segments of SW consecutive lanes (SW a power of two <= 64, segments aligned), `sub` = lane % SW.
+// Kogge-Stone inside the 16-lane rows (row_shr 1, 2, 4, 8), then the row totals: lane 15 of a row into the next row
+// (row_bcast15, rows 1 and 3), lane 31 into the upper half (row_bcast31).  OP(a, b): a is the EARLIER operand.
+template <int SW, class OP>
+__device__ __forceinline__ float seg_scan(float x, float identity, int sub, OP op) {
+  auto step = [&](auto ctrl_, int dlt) {
+    const float up = dpp<decltype(ctrl_)::value>(identity, x);
+    // inside a row the shift itself stops at the row's first lane; segments shorter than a row need the lane test
+    if (SW >= 16 || sub >= dlt) x = op(up, x);
+  };
+  if constexpr (SW >= 2) step(std::integral_constant<int, kRowShr1>{}, 1);
+  if constexpr (SW >= 4) step(std::integral_constant<int, kRowShr2>{}, 2);
+  if constexpr (SW >= 8) step(std::integral_constant<int, kRowShr4>{}, 4);
+  if constexpr (SW >= 16) step(std::integral_constant<int, kRowShr8>{}, 8);
+  if constexpr (SW >= 32) x = op(dpp<kRowBcast15, 0xA>(identity, x), x);
+  if constexpr (SW >= 64) x = op(dpp<kRowBcast31, 0xC>(identity, x), x);
+  return x;
 }
 
 // One chunk of SW consecutive samples of a ray, one sample per lane (lane `sub` of the SW-lane group).
@@ -39,17 +68,13 @@ __device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, f
     cb = 1.0f / (1.0f + expf(-q.z));
   }
   // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this ray
-  float p = ok ? (1.0f - alpha) + 1e-10f : 1.0f;
-#pragma unroll
-  for (int dlt = 1; dlt < SW; dlt <<= 1) {
-    const float up = __shfl_up(p, dlt, SW);
-    if (sub >= dlt) p *= up;
-  }
-  float excl = __shfl_up(p, 1, SW);
+  const float p = seg_scan<SW>(ok ? (1.0f - alpha) + 1e-10f : 1.0f, 1.0f, sub, [](float a, float b) { return a * b; });
+  float excl = dpp<kWaveShr1>(1.0f, p);          // the previous lane's inclusive product (lane 0: 1)
   if (sub == 0) excl = 1.0f;
   const float T = A.carry * excl;
   const float w = alpha * T;
-  A.carry = A.carry * __shfl(p, SW - 1, SW);
+  if constexpr (SW == 64)                        // (shorter segments are whole rays: nothing is carried)
+    A.carry = A.carry * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 63));
   if (ok) {
     A.r += w * cr; A.g += w * cg; A.b += w * cb;
     A.depth += w * zi;
@@ -59,49 +84,16 @@ __device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, f
   w_out = w;
 }
 
-// reduce the lanes' shares; lane 0 of the group (at least) ends up with the ray's totals
+// Reduce the lanes' shares: the LAST lane of each SW-lane group (sub == SW - 1) ends up with the ray's totals in A and its
+// disparity in `disp` (inclusive add-scans on DPP: five independent chains of log2 SW instructions, no LDS traffic).
 template <int SW>
-__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp) {
-  if constexpr (SW == 64) {
-    // Five sums over 64 lanes.  A plain butterfly is 5 x 6 ds_bpermute shuffles per ray, and those -- not the loads --
-    // bound the kernel; here each halving step also halves the lanes a value lives on (r, g, b to the lower half,
-    // depth, acc to the upper one, ...), so 9 shuffles do the five reductions and 4 more gather the totals in lane 0.
-    const int lane = static_cast<int>(threadIdx.x) & 63;
-    const bool up32 = lane & 32, up16 = lane & 16, up8 = lane & 8;
-    // step 32: lower half collects r, g, b; upper half depth, acc
-    const float x0 = __shfl_xor(up32 ? A.r : A.depth, 32, 64);
-    const float x1 = __shfl_xor(up32 ? A.g : A.acc, 32, 64);
-    const float x2 = __shfl_xor(A.b, 32, 64);
-    float v0 = up32 ? A.depth + x0 : A.r + x0;      // lower: r      upper: depth
-    float v1 = up32 ? A.acc + x1 : A.g + x1;        // lower: g      upper: acc
-    float v2 = A.b + x2;                            // lower: b      (upper: unused)
-    // step 16: lower half: lanes 0-15 keep r, g; 16-31 keep b.  upper half: 32-47 keep depth; 48-63 keep acc
-    const float y0 = __shfl_xor(up32 ? (up16 ? v0 : v1) : (up16 ? v0 : v2), 16, 64);
-    const float y1 = __shfl_xor(v1, 16, 64);
-    //   lane groups now:  [0,16): a = r, b = g   [16,32): a = b   [32,48): a = depth   [48,64): a = acc
-    float a = up32 ? (up16 ? v1 + y0 : v0 + y0) : (up16 ? v2 + y0 : v0 + y0);
-    float b = v1 + y1;                              // meaningful in [0,16) only
-    // step 8: [0,8) keeps r, [8,16) keeps g; the other groups just halve
-    const bool first16 = !up32 && !up16;
-    const float z0 = __shfl_xor(first16 ? (up8 ? a : b) : a, 8, 64);
-    a = first16 ? (up8 ? b + z0 : a + z0) : a + z0;
-    // steps 4, 2, 1: one value per lane
-    a += __shfl_xor(a, 4, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 1, 64);
-    // totals: r in lanes [0,8), g in [8,16), b in [16,32), depth in [32,48), acc in [48,64)
-    A.r = a;
-    A.g = __shfl(a, 8, 64);
-    A.b = __shfl(a, 16, 64);
-    A.depth = __shfl(a, 32, 64);
-    A.acc = __shfl(a, 48, 64);
-  } else {
-#pragma unroll
-    for (int m = SW >> 1; m > 0; m >>= 1) {
-      A.r += __shfl_xor(A.r, m, SW); A.g += __shfl_xor(A.g, m, SW); A.b += __shfl_xor(A.b, m, SW);
-      A.depth += __shfl_xor(A.depth, m, SW); A.acc += __shfl_xor(A.acc, m, SW);
-    }
-  }
+__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp, int sub) {
+  auto add = [](float a, float b) { return a + b; };
+  A.r = seg_scan<SW>(A.r, 0.0f, sub, add);
+  A.g = seg_scan<SW>(A.g, 0.0f, sub, add);
+  A.b = seg_scan<SW>(A.b, 0.0f, sub, add);
+  A.depth = seg_scan<SW>(A.depth, 0.0f, sub, add);
+  A.acc = seg_scan<SW>(A.acc, 0.0f, sub, add);
   const float q = A.depth / (A.acc + 1e-10f);
   disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));   // torch.max(1e-10, q) propagates NaN
   if (white_bkgd) { A.r += 1.0f - A.acc; A.g += 1.0f - A.acc; A.b += 1.0f - A.acc; }

@@ -1,6 +1,7 @@
 // Error string, version and device queries of libnerf_sampling_hip.so.
 #include "ns_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -48,10 +49,32 @@ hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
   return e;
 }
 
+// Diagnostic switches: read from the environment ONCE (first use), changed afterwards only through ns_debug_set -- no
+// getenv on the launch path.
+DebugFlags& debug_flags() {
+  static DebugFlags f = [] {
+    DebugFlags d{};
+    const char* v = std::getenv("NS_OB16_GENERIC");
+    d.generic_kernels = (v && v[0] == '1') ? 1 : 0;
+    v = std::getenv("NS_OB16_TILES");
+    d.prod_tiles = (v && (v[0] == '4' || v[0] == '5')) ? v[0] - '0' : 0;
+    return d;
+  }();
+  return f;
+}
+
 }  // namespace ns
 
 extern "C" {
 const char* ns_last_error(void) { return ns::g_err; }
+int ns_debug_set(const char* name, int value) {
+  if (!name) { ns::set_error("ns_debug_set: null name"); return NS_E_INVALID; }
+  ns::DebugFlags& f = ns::debug_flags();
+  if (!std::strcmp(name, "generic_kernels")) { f.generic_kernels = value ? 1 : 0; return NS_OK; }
+  if (!std::strcmp(name, "prod_tiles") && (value == 0 || value == 4 || value == 5)) { f.prod_tiles = value; return NS_OK; }
+  ns::set_error("ns_debug_set: unknown switch or value (%s = %d)", name, value);
+  return NS_E_INVALID;
+}
 int ns_version(void) { return 1; }
 int ns_device_cu_count(void) { return ns::cu_count(); }
 }

@@ -186,7 +186,7 @@ int dispatch(const ns_weights* net, NerfArgs& a, hipStream_t stream) {
 
 int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                          const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                         float* raw_dev, hipStream_t stream);
+                         float* raw_dev, hipStream_t stream, const ns_composite_args* comp);
 
 extern "C" {
 
@@ -205,7 +205,7 @@ int ns_nerf_forward(const ns_weights* net, const float* pts_dev, const float* o_
   NS_REQUIRE(net->out_ch != 4 || (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, nullptr, R * N, N, raw_dev,
-                                ns::as_stream(stream));
+                                ns::as_stream(stream), nullptr);
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;
@@ -224,7 +224,7 @@ int ns_nerf_forward_embedded(const ns_weights* net, const float* x_dev, int64_t 
   NS_REQUIRE(net->out_ch != 4 || (reinterpret_cast<uintptr_t>(raw_dev) & 15) == 0, "raw must be 16-byte aligned");
   if (net->layout == 16)
     return ns_nerf_forward_ob16(net, nullptr, nullptr, nullptr, nullptr, nullptr, x_dev, M, 1, raw_dev,
-                                ns::as_stream(stream));
+                                ns::as_stream(stream), nullptr);
   NerfArgs a{};
   a.stream = static_cast<const char*>(net->stream_dev);
   a.bias = net->bias_dev; a.n_slabs = net->n_slabs; a.bias_floats = net->bias_floats;

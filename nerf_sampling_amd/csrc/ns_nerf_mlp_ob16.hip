@@ -6,10 +6,10 @@
 // every A fragment (16 output rows x 32 input features, 1 KiB) read from LDS feeds 4 MFMAs; layers are walked one
 // 16-row output sub-block at a time (layer_ob16 in ns_mlp_engine.h; weight stream layout 16 of ns_pack.hip).
 #include "ns_common.h"
+#include "ns_composite_ray.h"
 #include "ns_mlp_engine.h"
+#include "ns_place.h"
 #include "ns_weights.h"
-
-#include <cstdlib>
 
 // This file is compiled twice: as itself, and with -DNS_OB16_TU_T5 as a second translation unit that holds only the
 // five-tile production kernels (the two units build in parallel; each is minutes of register allocation).
@@ -32,18 +32,28 @@ struct Nerf16Args {
   int64_t S;
   int N;
   float* raw;
+  // In-kernel compositing (the DepthNet branch of render_rays_test as ONE kernel, nerf_utils.py:836-865): comp != 0 runs
+  // raw2outputs (sampling_trainer.py:153-230) on the wave scan of ns_composite_ray.h in the epilogue -- raw then never
+  // leaves the CU (raw may be NULL).  comp == 1: depths from the array z [S];  comp == 2: sample_points_around_mean
+  // ("uniform", utils.py:231-241) evaluated in-kernel from the DepthNet depth mean [R] -- no z array exists.
+  // N must be a power of two <= 64 or a multiple of 64 (whole rays per 64-sample chunk, or whole chunks per ray).
+  int comp;
+  int n_shift;             // log2 N when N is a power of two, else -1
+  const float* mean;
+  float std_, lin_step;    // the grid linspace(-std, std, N - 1) and its step (correctly rounded on the host)
+  int white_bkgd;
+  float* rgb; int64_t rgb_stride;
+  float* disp; int64_t disp_stride;
+  float* weights;          // [S] or NULL
+  float* z_out;            // [S] or NULL (comp == 2: the depths the kernel placed)
+  float* pts_out;          // [S,3] or NULL
+  const float* sig_last;   // NULL, or [R,4]: element 3 of row r replaces sigma of ray r's last sample (the guard pass)
 };
 // the five-tile production kernel (PROD, 80 samples per wave): defined in the NS_OB16_TU_T5 unit
 int launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t stream);
 }  // namespace nsob16
 
 namespace {
-
-// diagnostic switch read per launch (tests compare the two paths in one process): "1" selects the generic kernel
-inline bool ns_env_flag(const char* name) {
-  const char* v = std::getenv(name);
-  return v && v[0] == '1';
-}
 
 using namespace nsmlp;
 
@@ -167,7 +177,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
 
-  // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 10 rows of 16 T floats]
+  // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 11 rows of 16 T floats]
+  //      [compositing records (a.comp): raw float4 per sample of the group | {z, dist} float2 per sample, two group parities
+  //       | sigma of a ray's last sample from the guard pass, one float per ray of the group, two parities]
   float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
   for (int i = threadIdx.x; i < a.bias_floats; i += NWAVES * 64) bias_lds[i] = a.bias[i];
   __syncthreads();
@@ -181,9 +193,34 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   };
   auto stash_put = [&](int t, int b, const Block& v) { *stash_at(t, b) = v.v; };
   auto stash_get = [&](int t, int b) -> Block { Block v; v.v = *stash_at(t, b); return v; };
-  // staging: value slot k (0..9) of sample j (0 .. 16 T - 1) of this wave's group at stage_base + k * kStageRow + j * 4
-  constexpr uint32_t kStageRow = (T > 4 ? 2 : 1) * 256;
-  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (10 * kStageRow);
+  // staging: value slot k (0..10) of sample j (0 .. 16 T - 1) of this wave's group at stage_base + k * kStageRow + j * 4
+  constexpr uint32_t kStageRow = T * 64, kStageRows = 11;
+  const uint32_t stage_base = stash_region + NWAVES * (T * 3 * 1024) + static_cast<uint32_t>(wave) * (kStageRows * kStageRow);
+  // compositing records (only allocated when a.comp): sample i (0 .. GS - 1) of the open group
+  constexpr int GS = NWAVES * T * 16;
+  const uint32_t comp_region = stash_region + NWAVES * (T * 3 * 1024) + NWAVES * (kStageRows * kStageRow);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef v4f __attribute__((address_space(3))) * CrawPtr;
+  typedef v2f __attribute__((address_space(3))) * CzdPtr;
+  // The lane id as a value the compiler cannot hoist: everything the compositing code derives from the lane (LDS record
+  // addresses per tile, the scan's lane predicates for six segment widths) would otherwise be computed ONCE before the
+  // group loop and kept alive across the ten layer statements -- which leave the compiler 32 VGPRs -- i.e. spilled to
+  // scratch and reloaded in the epilogue behind s_waitcnt vmcnt(0), waiting out the weight DMA in flight (measured: +1.5 ms
+  // per frame).  Two v_mbcnt per use instead.
+  auto opaque_lane = [] {
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)));
+  };
+  auto craw_at = [&](int i) -> CrawPtr { return reinterpret_cast<CrawPtr>(static_cast<uintptr_t>(comp_region + static_cast<uint32_t>(i) * 16u)); };
+  auto czd_at = [&](uint32_t par, int i) -> CzdPtr {
+    return reinterpret_cast<CzdPtr>(static_cast<uintptr_t>(comp_region + GS * 16u + (par * GS + static_cast<uint32_t>(i)) * 8u));
+  };
+  typedef float __attribute__((address_space(3))) * CsigPtr;
+  auto csig_at = [&](uint32_t par, int ray) -> CsigPtr {      // ray: index within the group (<= GS / 2 rays)
+    return reinterpret_cast<CsigPtr>(static_cast<uintptr_t>(comp_region + GS * 32u + (par * (GS / 2) + static_cast<uint32_t>(ray)) * 4u));
+  };
 
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
@@ -198,8 +235,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   };
   // Inputs of the NEXT group are fetched right after layer 0 of the current one by LDS-DMA (no registers held across
   // the network): lane j of the wave fetches the ten values of the j-th of the wave's 64 consecutive samples.
-  // pts mode: p 0..2, v 7..9;  (o, d, z) mode: o 0..2, d 3..5, z 6, v 7..9.
-  auto prefetch_round = [&](int64_t grp, int tile0) {     // the 64 lanes fetch tiles tile0 .. tile0 + 3 (clamped to T - 1)
+  // pts mode: p 0..2, v 7..9;  (o, d, z) mode: o 0..2, d 3..5, z 6, v 7..9;  compositing: slot 6 is the ray's DepthNet depth
+  // when the samples are placed in-kernel (comp == 2), slot 10 the NEXT sample's depth when they come from z (comp == 1).
+  auto prefetch_round = [&](int64_t grp, int tile0) {     // the active lanes fetch tiles tile0 .. tile0 + 3 (clamped to T - 1)
     bool valid;
     const int tl = tile0 + (lane >> 4);
     const int64_t sidx = sample_of(grp, tl < T ? tl : T - 1, lane & 15, valid);   // (surplus lanes re-fetch, harmlessly)
@@ -214,7 +252,10 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { put(c, a.o + ray * 3 + c); put(3 + c, a.d + ray * 3 + c); }
-      put(6, a.z + sidx);
+      if (a.comp == 2) put(6, a.mean + ray);
+      else put(6, a.z + sidx);
+      if (a.comp == 1) put(10, a.z + (sidx + 1 < a.S ? sidx + 1 : sidx));
+      else if (a.sig_last) put(10, a.sig_last + ray * 4 + 3);
     }
     if (a.use_viewdirs) {
 #pragma unroll
@@ -224,7 +265,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   auto prefetch = [&](int64_t grp) {
     if constexpr (!EMBEDDED) {
       prefetch_round(grp, 0);
-      if constexpr (T > 4) prefetch_round(grp, 4);
+      if constexpr (T > 4) {      // the fifth tile: 16 lanes (a staging row holds exactly the wave's 16 T samples)
+        if (lane < 16 * (T - 4)) prefetch_round(grp, 4);
+      }
     }
   };
   auto staged = [&](int t, int slot) -> float {
@@ -234,7 +277,8 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
 
   prefetch(blockIdx.x);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  uint32_t par = 0;      // parity of the group pass: which {z, dist} record buffer this group writes (compositing only)
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x, par ^= 1u) {
     Block xe[T][2];   // embedded point (63 -> 64 features); registers for layer 0 only
     // Non-finite inputs: the reference's arithmetic turns a NaN / inf coordinate into NaN in all four outputs (sin / cos,
     // nn.Linear and torch.relu all propagate it).  Here the packed-int16 ReLU would drop the NEGATIVE NaNs the matrix
@@ -263,12 +307,52 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       // embedded or stashed: read tile by tile, each read sat right in front of its first use (an exposed LDS latency per
       // value, ~3 % of the kernel: nothing else runs on this SIMD while the lone wave waits).
       float P[T][3], V[T][3];          // (compile-time indices only: a runtime index would park the arrays in scratch)
+      if (a.comp) {   // (wave-uniform)
+        // Sample placement + the compositing record {z, dist * |d|} of every sample of the wave, ONE SAMPLE PER LANE (64 at a
+        // time: the tile layout below holds a sample on four lanes, and a per-tile evaluation would cost T times this):
+        // sample i of the wave's 16 T on lane i % 64 of pass i / 64.  The records go to LDS -- the epilogue composites from
+        // them, and the tiles read their depth back from there a few lines down (same wave: LDS order suffices).
+        const int lo = opaque_lane();
+        constexpr int kPasses = (16 * T + 63) / 64;
+#pragma unroll
+        for (int pass = 0; pass < kPasses; ++pass) {
+          const int i = pass * 64 + lo;
+          if (i < 16 * T) {
+            auto st = [&](int slot) -> float {
+              return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
+                  static_cast<uintptr_t>(stage_base + slot * kStageRow + i * 4));
+            };
+            const int64_t s_raw = (grp * NWAVES + wave) * (16 * T) + i;
+            const bool valid = s_raw < a.S;
+            const int64_t sidx = valid ? s_raw : a.S - 1;
+            const int j = a.n_shift >= 0 ? static_cast<int>(static_cast<uint32_t>(sidx) & static_cast<uint32_t>(a.N - 1))
+                                         : static_cast<int>(sidx % a.N);
+            float zz = st(6), znext;
+            if (a.comp == 2) {      // sample_points_around_mean("uniform"): depths j and j + 1 of the ray from its mean
+              const float m = zz;
+              zz = nsplace::uniform_z(m, a.std_, a.lin_step, a.N - 1, j);
+              znext = nsplace::uniform_z(m, a.std_, a.lin_step, a.N - 1, j + 1);
+            } else {
+              znext = st(10);
+            }
+            const float dist_raw = (j < a.N - 1) ? znext - zz : 1e10f;      // sampling_trainer.py:176-180
+            const float d0 = st(3), d1 = st(4), d2 = st(5);
+            *czd_at(par, wave * (16 * T) + i) = v2f{zz, dist_raw * nscomp::ray_norm(d0, d1, d2)};
+            if (a.sig_last && j == a.N - 1) *csig_at(par, (wave * (16 * T) + i) >> a.n_shift) = st(10);
+            if (valid && a.z_out) a.z_out[sidx] = zz;
+            if (valid && a.pts_out) {
+              float* q = a.pts_out + sidx * 3;
+              q[0] = st(0) + d0 * zz; q[1] = st(1) + d1 * zz; q[2] = st(2) + d2 * zz;
+            }
+          }
+        }
+      }
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
         if (a.pts) {
           static_for<3>([&](auto c_) { P[t][decltype(c_)::value] = staged(t, decltype(c_)::value); });
         } else {
-          const float zz = staged(t, 6);
+          const float zz = a.comp ? (*czd_at(par, (wave * T + t) * 16 + n)).x : staged(t, 6);
           static_for<3>([&](auto c_) {
             constexpr int c = decltype(c_)::value;
             P[t][c] = staged(t, c) + staged(t, 3 + c) * zz;
@@ -294,16 +378,6 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         }
       });
       Block ve0[1];
-#ifdef NS_EXP_NOEMBED      // timing ablation: no positional encoding (results are wrong)
-      static_for<T>([&](auto t_) {
-        constexpr int t = decltype(t_)::value;
-        float x8[8];
-        static_for<8>([&](auto e_) { x8[decltype(e_)::value] = P[t][decltype(e_)::value % 3] + V[t][decltype(e_)::value % 3]; });
-        xe[t][0] = M::from_f32(x8); xe[t][1] = xe[t][0];
-        stash_put(t, 0, xe[t][0]); stash_put(t, 1, xe[t][1]); stash_put(t, 2, xe[t][0]);
-      });
-#endif
-#ifndef NS_EXP_NOEMBED
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
         bool ok = finite(P[t][0]) && finite(P[t][1]) && finite(P[t][2]);
@@ -316,7 +390,6 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         }
         if (!ok) bad |= 1u << t;
       });
-#endif
     }
 
     const float* bias = bias_lds;
@@ -368,9 +441,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     { layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16; }
     // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
     // have been consumed (they fed the embeddings above)
-#ifndef NS_EXP_NOPREFETCH
     if constexpr (!(PROD && NS_OB16_ASM && NS_OB16_ASM_ALL && NS_OB16_PREFETCH_EARLY)) prefetch(grp + gridDim.x);
-#endif
     int l = 1;
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE
     if constexpr (PROD) {
@@ -458,19 +529,62 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hA, last, in_B);
     }
 
-    if (g == 0) {
+    bool comp = false;
+    if constexpr (!EMBEDDED) comp = a.comp != 0;
+    const int le = opaque_lane();      // the lane id of the epilogue (see opaque_lane)
+    if (le < 16) {                     // lane group g == 0 holds the outputs: rows 0..2 = rgb, sigma from the view layer
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
         bool valid;
-        const int64_t sidx = sample_of(grp, t, n, valid);
+        const int64_t sidx = sample_of(grp, t, le, valid);
         float4 o4 = make_float4(last[t][0], last[t][1], last[t][2], sigma[t]);
         if ((bad >> t) & 1u) { const float q = __builtin_nanf(""); o4 = make_float4(q, q, q, q); }
-#ifdef NS_EXP_NOSTORE      // timing ablation: raw never leaves the kernel (what would compositing in the epilogue be worth?)
-        if (valid && o4.x == 123456.0f) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
-#else
-        if (valid) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
-#endif
+        if (comp) *craw_at((wave * T + t) * 16 + le) = v4f{o4.x, o4.y, o4.z, o4.w};
+        if (valid && a.raw) reinterpret_cast<float4*>(a.raw)[sidx] = o4;
       });
+    }
+    if constexpr (!EMBEDDED) {
+      if (comp) {
+        // raw2outputs in the epilogue (sampling_trainer.py:153-230): the group's samples are T chunks of 64 consecutive
+        // samples -- whole rays (N <= 64, a power of two) -- one chunk per wave pass, composited by the lane-level code the
+        // stand-alone kernel runs (ns_composite_ray.h: same operations in the same order, so bit-identical to it).
+        // Four tiles: a wave's chunk is its own 64 samples, the wave's own LDS order suffices; five tiles: chunks straddle
+        // waves, one s_barrier (all four waves reach it: the group loop is workgroup-uniform).
+        if constexpr (T == 4) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        auto composite = [&](auto sw_, int c) {
+          constexpr int SW = decltype(sw_)::value;
+          const int i = c * 64 + le;
+          const int64_t s = grp * GS + i;
+          const bool ok = s < a.S;
+          const v4f qv = *craw_at(i);
+          const v2f zd = *czd_at(par, i);
+          float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
+          if (a.sig_last && (le & (SW - 1)) == SW - 1) q.w = *csig_at(par, i / SW);      // the guard pass's sigma_last
+          nscomp::RayAccum A;
+          float alpha, w, disp;
+          const int sub = le & (SW - 1);
+          nscomp::composite_chunk<SW>(A, ok, sub, q, zd.x, zd.y, 1.0f, 0.0f, false, alpha, w);
+          if (ok && a.weights) a.weights[s] = w;
+          nscomp::composite_finish<SW>(A, a.white_bkgd, disp, sub);
+          if (ok && sub == SW - 1) {
+            const int64_t r = s / SW;      // N == SW
+            float* prgb = a.rgb + r * a.rgb_stride;
+            prgb[0] = A.r; prgb[1] = A.g; prgb[2] = A.b;
+            a.disp[r * a.disp_stride] = disp;
+          }
+        };
+        for (int c = wave; c < T; c += NWAVES) {
+          switch (a.N) {
+            case 64: composite(std::integral_constant<int, 64>{}, c); break;
+            case 32: composite(std::integral_constant<int, 32>{}, c); break;
+            case 16: composite(std::integral_constant<int, 16>{}, c); break;
+            case 8: composite(std::integral_constant<int, 8>{}, c); break;
+            case 4: composite(std::integral_constant<int, 4>{}, c); break;
+            default: composite(std::integral_constant<int, 2>{}, c); break;
+          }
+        }
+      }
     }
   }
   ring.finish();
@@ -489,7 +603,8 @@ template <class M, int NKB, bool EMB, bool PROD = false, int TT = kT>
 int launch(Nerf16Args& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * TT * 3 * 1024 +
-                     static_cast<size_t>(kWaves) * 10 * (TT > 4 ? 512 : 256);   // ring | bias | embedding stash | input staging
+                     static_cast<size_t>(kWaves) * 11 * (TT * 64) +      // ring | bias | embedding stash | input staging
+                     (a.comp && !EMB ? static_cast<size_t>(kWaves) * TT * 16 * 36 : 0);   // | compositing records (32 B per sample + 8 B per ray pair)
   if (lds > 160 * 1024) {
     ns::set_error("ns_nerf_forward: %zu bytes of LDS needed (too deep a network for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
@@ -510,7 +625,7 @@ int launch(Nerf16Args& a, hipStream_t stream) {
 template <class M, bool EMB>
 int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
 #if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE && NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
-  if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC")) {
+  if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns::debug_flags().generic_kernels) {
     // the production network: hand-scheduled layers, four or five 16-sample tiles per wave.  Five tiles read 20 % fewer
     // weight fragments and refill bytes per sample (-2.5 % per frame on the final build, profiles/r03c_ab_tiles_final_build.log);
     // the persistent grid runs ceil(groups / CUs) rounds of 256 (320) samples per workgroup, so the choice is made per
@@ -520,7 +635,7 @@ int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
     auto rounds = [&](int64_t per_group) { const int64_t g = (a.S + per_group - 1) / per_group; return (g + cus - 1) / cus; };
     const double t4 = static_cast<double>(rounds(kWaves * 4 * 16)) * 4.0, t5 = static_cast<double>(rounds(kWaves * 5 * 16)) * 5.0 * 0.975;
     int tiles = NS_OB16_PROD_T ? NS_OB16_PROD_T : (t5 < t4 ? 5 : 4);
-    if (const char* v = std::getenv("NS_OB16_TILES")) tiles = (v[0] == '5') ? 5 : 4;   // diagnostic override
+    if (ns::debug_flags().prod_tiles) tiles = ns::debug_flags().prod_tiles;   // diagnostic override (ns_debug_set)
     if (tiles == 5) return nsob16::launch_prod_t5(M::kDtype, EMB, a, stream);
     return launch<M, 8, EMB, true, 4>(a, stream);
   }
@@ -541,10 +656,26 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
                        float* raw_dev, hipStream_t stream);
 
+// which (network, sample count) pairs the kernel composites itself (see Nerf16Args::comp)
+bool ns_nerf_can_composite(const ns_weights* net, int N) {
+  return net && net->kind == NS_KIND_NERF && net->layout == 16 && (net->dtype == NS_DTYPE_BF16 || net->dtype == NS_DTYPE_F16) &&
+         net->use_viewdirs && net->out_ch == 4 && N >= 2 && N <= 64 && (N & (N - 1)) == 0;
+}
+
 // called by ns_nerf_forward / ns_nerf_forward_embedded for handles packed with layout 16 (arguments validated there)
 int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                          const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                         float* raw_dev, hipStream_t stream) {
+                         float* raw_dev, hipStream_t stream, const ns_composite_args* comp) {
+  if (comp) {
+    if (!ns_nerf_can_composite(net, N)) {
+      ns::set_error("in-kernel compositing needs a 16-bit NeRF handle with view directions and N a power of two in [2, 64] (N = %d)", N);
+      return NS_E_UNSUPPORTED;
+    }
+    if (pts_dev || x90_dev || !(o_dev && d_dev) || !(z_dev || comp->mean_dev) || !(comp->rgb_dev && comp->disp_dev)) {
+      ns::set_error("in-kernel compositing needs rays (o, d), depths (z or mean) and the rgb / disp outputs");
+      return NS_E_INVALID;
+    }
+  }
   if (net->dtype == NS_DTYPE_F16X3)   // split fp16 operands: ns_nerf_mlp_x3.hip
     return ns_nerf_forward_x3(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, x90_dev, S, N, raw_dev, stream);
   if (ob16_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs) != static_cast<int>(net->n_slabs)) {
@@ -559,6 +690,16 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
   a.x_stride = net->use_viewdirs ? 90 : 63;
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
+  if (comp) {
+    a.comp = comp->mean_dev ? 2 : 1;
+    a.mean = comp->mean_dev; a.std_ = comp->std_; a.lin_step = nsplace::linspace_step_of(-comp->std_, comp->std_, N - 1);
+    a.n_shift = -1;
+    for (int k = 0; k < 31; ++k) if (N == (1 << k)) a.n_shift = k;
+    a.white_bkgd = comp->white_bkgd;
+    a.rgb = comp->rgb_dev; a.rgb_stride = comp->rgb_stride; a.disp = comp->disp_dev; a.disp_stride = comp->disp_stride;
+    a.weights = comp->weights_dev; a.z_out = comp->z_out_dev; a.pts_out = comp->pts_out_dev;
+    a.sig_last = comp->sigma_last_dev;
+  }
   const bool emb = x90_dev != nullptr;
 #ifdef NS_OB16_VARIANT_BUILD   // tools/build_asm_variant.sh: only the kernel under test is instantiated (a 20 s build)
   if (net->dtype == NS_DTYPE_BF16 && !emb && net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs)

@@ -20,10 +20,6 @@ constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + a
 #define NS_OB16_ASM 1        // 1: the production network's hidden layers run the generated streams of ns_ob16_asm.inc
 #endif
 
-inline bool ns_env_flag(const char* name) {   // diagnostic switch read per launch: NS_OB16_GENERIC=1 selects the generic kernel
-  const char* v = std::getenv(name);
-  return v && v[0] == '1';
-}
 
 #if NS_OB16_ASM
 }  // namespace
@@ -350,7 +346,7 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
   a.S = S; a.N = N; a.raw = raw_dev;
   const bool emb = x90_dev != nullptr, wide = net->width == 256;
 #if NS_OB16_ASM
-  if (wide && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns_env_flag("NS_OB16_GENERIC"))
+  if (wide && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns::debug_flags().generic_kernels)
     return emb ? launch<8, true, true>(a, stream) : launch<8, false, true>(a, stream);   // the production network
 #endif
   if (emb) return wide ? launch<8, true>(a, stream) : launch<4, true>(a, stream);

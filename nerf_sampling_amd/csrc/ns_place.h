@@ -1,0 +1,44 @@
+// Sample placement of sample_points_around_mean("uniform") (utils.py:231-241) as lane-level building blocks, shared by the
+// stand-alone placement kernels (ns_rays.hip) and the one-kernel renderer (ns_nerf_mlp_ob16.hip), so both place a sample
+// with the same fp32 operations (translation units that include this are built with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nsplace {
+
+// torch.linspace(start, end, steps)[i] for fp32 (ATen RangeFactories: two-sided evaluation)
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+  if (steps <= 1) return start;
+  const float step = (end - start) / static_cast<float>(steps - 1);
+  return (i < steps / 2) ? start + step * static_cast<float>(i)
+                         : end - step * static_cast<float>(steps - i - 1);
+}
+// the same with step = (end - start) / float(steps - 1) precomputed (a correctly rounded fp32 division on either side)
+__device__ __forceinline__ float linspace_step(float start, float end, float step, int steps, int i) {
+  if (steps <= 1) return start;
+  return (i < steps / 2) ? start + step * static_cast<float>(i)
+                         : end - step * static_cast<float>(steps - i - 1);
+}
+__host__ inline float linspace_step_of(float start, float end, int steps) {
+  return steps <= 1 ? 0.0f : (end - start) / static_cast<float>(steps - 1);
+}
+
+// z[j], j = 0 .. steps, of  clip(sort(cat[m + linspace(-std, std, steps), m]), 2, 6)  (steps = n_samples - 1 >= 1).
+// The grid a_i = m + g_i is non-decreasing, so the mean is merged at its rank p = #{i : a_i < m} instead of sorting:
+// z[j] = a_j for j < p, m for j == p, a_{j-1} for j > p.  "j < p" <=> a_j < m and "j > p" <=> !(a_{j-1} < m), so no rank
+// search is needed.  A NaN mean gives NaN everywhere (the clip would turn it into 2).
+__device__ __forceinline__ float uniform_z(float m, float std_, float step, int steps, int j) {
+  float v = m;
+  if (j < steps) {
+    const float b = m + linspace_step(-std_, std_, step, steps, j);
+    if (b < m) v = b;
+  }
+  if (v == m && j >= 1) {          // (v != m: the first branch fired, j < p)
+    const float a = m + linspace_step(-std_, std_, step, steps, j - 1);
+    if (!(a < m)) v = a;
+  }
+  v = fminf(fmaxf(v, 2.0f), 6.0f);  // hard-coded clip, utils.py:240
+  return (m != m) ? m : v;
+}
+
+}  // namespace nsplace

@@ -3,18 +3,13 @@
 // ray, grid-stride.  Built with -ffp-contract=off so that mul/add stay separate roundings like
 // the reference's eager PyTorch arithmetic.
 #include "ns_common.h"
+#include "ns_place.h"
 
 namespace {
 
 constexpr int kBlock = 256;
 
-// torch.linspace(start, end, steps)[i] for fp32 (ATen RangeFactories: two-sided evaluation)
-__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
-  if (steps <= 1) return start;
-  const float step = (end - start) / static_cast<float>(steps - 1);
-  return (i < steps / 2) ? start + step * static_cast<float>(i)
-                         : end - step * static_cast<float>(steps - i - 1);
-}
+using nsplace::linspace_at;
 
 struct Cam {
   float fx, fy, cx, cy;
@@ -118,11 +113,12 @@ posenc_kernel(const float* __restrict__ x, int64_t M, int d, int L, float* __res
 }
 
 // a5: utils.py:220-244, values before any sort.  UNIFORM is emitted already sorted + clipped
-// (the grid is increasing, so the mean is merged at its rank instead of sorting).
+// (the grid is increasing, so the mean is merged at its rank instead of sorting: nsplace::uniform_z).
 __global__ void __launch_bounds__(kBlock)
 place_z_kernel(int mode, const float* __restrict__ mean, const float* __restrict__ noise,
                int64_t R, int N, float std_, float* __restrict__ z) {
   const int64_t total = R * N;
+  const float step = N > 2 ? (std_ - (-std_)) / static_cast<float>(N - 2) : 0.0f;   // linspace(-std, std, N - 1)
   for (int64_t e = blockIdx.x * (int64_t)kBlock + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * kBlock) {
     const int64_t r = e / N;
@@ -134,50 +130,37 @@ place_z_kernel(int mode, const float* __restrict__ mean, const float* __restrict
     } else if (mode == NS_MODE_GAUSSIAN) {
       v = (j < N - 1) ? m + std_ * noise[r * (N - 1) + j] : m;
     } else {
-      const int steps = N - 1;
-      // rank of the mean among a_i = m + grid_i (non-decreasing in i): p = #{a_i < m}
-      int lo = 0, hi = steps;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (m + linspace_at(-std_, std_, steps, mid) < m) lo = mid + 1; else hi = mid;
-      }
-      const int p = lo;
-      if (j < p) v = m + linspace_at(-std_, std_, steps, j);
-      else if (j == p) v = m;
-      else v = m + linspace_at(-std_, std_, steps, j - 1);
-      v = fminf(fmaxf(v, 2.0f), 6.0f);  // hard-coded clip, utils.py:240 (NaN stays NaN below)
-      if (m != m) v = m;
+      v = nsplace::uniform_z(m, std_, step, N - 1, j);   // already sorted + clipped (ns_place.h)
     }
     z[e] = v;
   }
 }
 
-// UNIFORM mode, N % 4 == 0: one thread per four consecutive samples of a ray -- the rank search runs once per four
-// outputs and the store is a float4 (the generic kernel above is ~6x off the HBM rate at N = 64).
+// UNIFORM mode, N % 4 == 0: one thread per four consecutive samples of a ray, the store is a float4 (the generic kernel
+// above is ~6x off the HBM rate at N = 64).
 __global__ void __launch_bounds__(kBlock)
 place_z_uniform4_kernel(const float* __restrict__ mean, int64_t R, int N, float std_, float4* __restrict__ z4) {
   const int q = N >> 2, steps = N - 1;
+  const float step = steps > 1 ? (std_ - (-std_)) / static_cast<float>(steps - 1) : 0.0f;
   const int64_t total = R * q;
   for (int64_t e = blockIdx.x * (int64_t)kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
     const int64_t r = e / q;
     const int j0 = 4 * static_cast<int>(e - r * q);
     const float m = mean[r];
-    int lo = 0, hi = steps;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (m + linspace_at(-std_, std_, steps, mid) < m) lo = mid + 1; else hi = mid;
-    }
-    const int p = lo;
     float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int j = j0 + k;
-      float x = (j < p) ? m + linspace_at(-std_, std_, steps, j) : (j == p ? m : m + linspace_at(-std_, std_, steps, j - 1));
-      x = fminf(fmaxf(x, 2.0f), 6.0f);
-      v[k] = (m != m) ? m : x;
-    }
+    for (int k = 0; k < 4; ++k) v[k] = nsplace::uniform_z(m, std_, step, steps, j0 + k);
     z4[e] = make_float4(v[0], v[1], v[2], v[3]);
   }
+}
+
+// the LAST sample of every ray only (the guard pass of ns_render_rays_*: ns_render_args::nerf_guard)
+__global__ void __launch_bounds__(kBlock)
+place_last_kernel(const float* __restrict__ mean, int64_t R, int N, float std_, float* __restrict__ z_last) {
+  const int steps = N - 1;
+  const float step = steps > 1 ? (std_ - (-std_)) / static_cast<float>(steps - 1) : 0.0f;
+  for (int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x; r < R; r += (int64_t)gridDim.x * kBlock)
+    z_last[r] = nsplace::uniform_z(mean[r], std_, step, steps, N - 1);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -383,3 +366,12 @@ int ns_coarse_z_scalar(float near_, float far_, int64_t R, int N, int lindisp, c
 }
 
 }  // extern "C"
+
+#include "ns_weights.h"
+int ns_place_last_sample(const float* mean_dev, int64_t R, int N, float std_, float* z_last_dev, void* stream) {
+  NS_REQUIRE(R >= 0 && N >= 2 && mean_dev && z_last_dev, "bad arguments");
+  if (R == 0) return NS_OK;
+  place_last_kernel<<<ns::ew_grid(R, kBlock), kBlock, 0, ns::as_stream(stream)>>>(mean_dev, R, N, std_, z_last_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}

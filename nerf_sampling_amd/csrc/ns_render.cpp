@@ -3,12 +3,16 @@
 #include "ns_common.h"
 #include "ns_weights.h"
 
+int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
+                         const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
+                         float* raw_dev, hipStream_t stream, const ns_composite_args* comp);
+
 namespace {
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~static_cast<int64_t>(255); }
 
 struct Layout {
-  int64_t o, d, view, mean, z, raw, total;
+  int64_t o, d, view, mean, z_last, raw_last, z, raw, total;
 };
 
 Layout layout(int64_t R, int N) {
@@ -18,10 +22,31 @@ Layout layout(int64_t R, int N) {
   l.d = off; off += align256(R * 3 * 4);
   l.view = off; off += align256(R * 3 * 4);
   l.mean = off; off += align256(R * 4);
+  l.z_last = off; off += align256(R * 4);          // the guard pass (ns_render_args::nerf_guard): depth and raw of every
+  l.raw_last = off; off += align256(R * 16);       // ray's last sample
   l.z = off; off += align256(R * N * 4);
   l.raw = off; off += align256(R * N * 16);
   l.total = off;
   return l;
+}
+
+// The guard pass: the last sample of every ray through a second, fp32-grade (F16X3) handle of the same network; its raw
+// lands in raw_last [R,4].  (nerf_utils.py:836-865 composites that sample with dist = 1e10, sampling_trainer.py:176-180.)
+int guard_pass(const ns_render_args* a, const float* o, const float* d, const float* view, const float* mean, int64_t R,
+               int N, float* z_last, float* raw_last, void* stream) {
+  const ns_weights* gnet = a->nerf_guard;
+  if (!(gnet->kind == NS_KIND_NERF && gnet->out_ch == 4 && gnet->use_viewdirs && gnet->width == a->nerf->width &&
+        gnet->depth == a->nerf->depth && gnet->skip_mask == a->nerf->skip_mask)) {
+    ns::set_error("nerf_guard must be another packing of the same network (a NeRF with view directions, same D / W / skips)");
+    return NS_E_INVALID;
+  }
+  if (a->mode != NS_MODE_UNIFORM || N < 2) {
+    ns::set_error("nerf_guard: the guard pass is defined for uniform placement with n_samples >= 2");
+    return NS_E_UNSUPPORTED;
+  }
+  int rc = ns_place_last_sample(mean, R, N, a->std_, z_last, stream);
+  if (rc != NS_OK) return rc;
+  return ns_nerf_forward(gnet, nullptr, o, d, z_last, view, R, 1, raw_last, stream);
 }
 
 }  // namespace
@@ -78,9 +103,83 @@ int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   rc = ns_nerf_forward(a->nerf, nullptr, o, d, z, view, R, N, raw, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
+  if (a->nerf_guard) {
+    float* raw_last = reinterpret_cast<float*>(ws + l.raw_last);
+    rc = guard_pass(a, o, d, view, mean, R, N, reinterpret_cast<float*>(ws + l.z_last), raw_last, stream);
+    if (rc != NS_OK) return rc;
+    rc = ns_patch_sigma_last(raw, raw_last, R, N, stream);
+    if (rc != NS_OK) return rc;
+  }
   return ns_raw2outputs_strided(raw, z, d, nullptr, R, N, a->white_bkgd, a->rgb_dev, a->rgb_stride ? a->rgb_stride : 3,
                                 a->disp_dev, a->disp_stride ? a->disp_stride : 1, nullptr, nullptr, nullptr,
                                 a->weights_dev, stream);
+}
+
+// ---- the same branch as ONE kernel per ray tile: rays -> DepthNet -> [placement + radiance-field
+// MLP + compositing in one persistent kernel].  Per-sample data (z, pts, raw, weights) never reaches HBM unless asked for.
+int ns_render_fused_supported(const ns_weights* nerf, int mode, int N) {
+  return mode == NS_MODE_UNIFORM && ns_nerf_can_composite(nerf, N) ? 1 : 0;
+}
+
+int64_t ns_render_fused_workspace_bytes(int64_t R) {
+  if (R < 0) return 0;
+  return 3 * align256(R * 12) + 2 * align256(R * 4) + align256(R * 16);   // o, d, viewdirs | DepthNet depth | guard: z_last, raw_last
+}
+
+int ns_render_rays_fused(const ns_render_args* a, void* stream) {
+  NS_REQUIRE(a, "null args");
+  NS_REQUIRE(a->depthnet && a->nerf, "both networks are required");
+  if (!ns_render_fused_supported(a->nerf, a->mode, a->N)) {
+    ns::set_error("ns_render_rays_fused: uniform placement, a 16-bit NeRF handle with view directions and n_samples a power "
+                  "of two in [2, 64] are required (mode %d, N %d); use ns_render_rays_depthnet", a->mode, a->N);
+    return NS_E_UNSUPPORTED;
+  }
+  NS_REQUIRE(!a->noise_dev, "uniform placement takes no noise");
+  if (a->o_dev == nullptr ? (a->row1 == a->row0 || a->W == 0) : a->R == 0) return NS_OK;  // nothing to render
+  NS_REQUIRE(a->workspace_dev && a->rgb_dev && a->disp_dev, "workspace, rgb and disp are required");
+  int64_t R = a->R;
+  if (!a->o_dev) {
+    NS_REQUIRE(a->row0 >= 0 && a->row1 <= a->H && a->row0 <= a->row1 && a->W > 0, "bad camera rows");
+    R = static_cast<int64_t>(a->row1 - a->row0) * a->W;
+  } else {
+    NS_REQUIRE(a->d_dev && a->viewdirs_dev, "explicit rays need o, d and viewdirs");
+  }
+  if (R == 0) return NS_OK;
+  char* ws = static_cast<char*>(a->workspace_dev);
+  NS_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "workspace must be 256-byte aligned");
+  const float* o = a->o_dev;
+  const float* d = a->d_dev;
+  const float* view = a->viewdirs_dev;
+  int rc;
+  if (!o) {
+    float* wo = reinterpret_cast<float*>(ws);
+    float* wd = reinterpret_cast<float*>(ws + align256(R * 12));
+    float* wv = reinterpret_cast<float*>(ws + 2 * align256(R * 12));
+    rc = ns_get_rays(a->H, a->W, a->fx, a->fy, a->cx, a->cy, a->c2w, a->row0, a->row1, a->near_, a->far_, wo, wd, wv,
+                     nullptr, stream);
+    if (rc != NS_OK) return rc;
+    o = wo; d = wd; view = wv;
+  }
+  float* mean = reinterpret_cast<float*>(ws + 3 * align256(R * 12));
+  rc = ns_depthnet_forward(a->depthnet, o, d, R, a->near_, a->far_, a->sphere_radius, mean, stream);
+  if (rc != NS_OK) return rc;
+  ns_composite_args c{};
+  c.mean_dev = mean; c.std_ = a->std_; c.white_bkgd = a->white_bkgd;
+  c.rgb_dev = a->rgb_dev; c.rgb_stride = a->rgb_stride ? a->rgb_stride : 3;
+  c.disp_dev = a->disp_dev; c.disp_stride = a->disp_stride ? a->disp_stride : 1;
+  c.weights_dev = a->weights_dev; c.z_out_dev = a->z_dev; c.pts_out_dev = a->pts_dev;
+  if (a->nerf_guard) {     // (before the event pair: the pair times the fused kernel alone)
+    float* z_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + align256(R * 4));
+    float* raw_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + 2 * align256(R * 4));
+    rc = guard_pass(a, o, d, view, mean, R, a->N, z_last, raw_last, stream);
+    if (rc != NS_OK) return rc;
+    c.sigma_last_dev = raw_last;
+  }
+  if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
+  rc = ns_nerf_forward_ob16(a->nerf, nullptr, o, d, nullptr, view, nullptr, R * a->N, a->N, nullptr, ns::as_stream(stream), &c);
+  if (rc != NS_OK) return rc;
+  if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
+  return NS_OK;
 }
 
 int64_t ns_hier_workspace_bytes(int64_t R, int Nc, int Nf) {
@@ -125,8 +224,10 @@ int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   // coarse pass (Trainer.py:579-649); its rgb/disp are not part of the 8-tuple and are not produced
   rc = ns_coarse_z_scalar(a->near_, a->far_, R, Nc, a->lindisp, a->t_rand_dev, z_c, stream);
   if (rc != NS_OK) return rc;
+  if (a->ev_coarse_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_coarse_begin), ns::as_stream(stream)));
   rc = ns_nerf_forward(a->coarse, nullptr, o, d, z_c, view, R, Nc, raw_c, stream);
   if (rc != NS_OK) return rc;
+  if (a->ev_coarse_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_coarse_end), ns::as_stream(stream)));
   rc = ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, w_c,
                       stream);
   if (rc != NS_OK) return rc;

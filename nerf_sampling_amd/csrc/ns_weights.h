@@ -20,3 +20,23 @@ struct ns_weights {
 };
 
 enum { NS_KIND_NERF = 0, NS_KIND_DEPTHNET = 1 };
+
+// Per-ray outputs of a radiance-field pass that composites in its own epilogue (internal: ns_render.cpp -> the 16-bit MLP
+// kernel).  mean_dev != NULL: the kernel also PLACES the samples (sample_points_around_mean "uniform") from the DepthNet
+// depth; otherwise depths come from the z array given to the forward call.
+struct ns_composite_args {
+  const float* mean_dev;   // [R] or NULL
+  float std_;
+  int white_bkgd;
+  float* rgb_dev; int64_t rgb_stride;
+  float* disp_dev; int64_t disp_stride;
+  float* weights_dev;      // [R,N] or NULL
+  float* z_out_dev;        // [R,N] or NULL
+  float* pts_out_dev;      // [R,N,3] or NULL
+  const float* sigma_last_dev;   // NULL, or [R,4] raw of every ray's LAST sample from the guard pass: its sigma (element 3)
+                                 // replaces the kernel's own for that sample (ns_render_args::nerf_guard)
+};
+// internal helpers of the guard pass (ns_rays.hip, ns_composite.hip)
+int ns_place_last_sample(const float* mean_dev, int64_t R, int N, float std_, float* z_last_dev, void* stream);
+int ns_patch_sigma_last(float* raw_dev, const float* raw_last_dev, int64_t R, int N, void* stream);
+bool ns_nerf_can_composite(const ns_weights* net, int N);

@@ -54,7 +54,36 @@ _DEPTHNET_PAIRING = {"bf16": "f16"}
 
 def depthnet_dtype_for(name: Optional[str] = None) -> str:
     name = name or _compute_dtype
+    if _psnr_guard and name in ("bf16", "f16"):
+        return "f16x3"
     return _DEPTHNET_PAIRING.get(name, name)
+
+
+# PSNR guard of the 16-bit compute dtypes.  north_star's acceptance bar is a scene PSNR within 0.05 dB of the reference's; on
+# a fitted scene that renders at 28-30 dB, plain 16-bit operands sit AT that bar (tools/scene_psnr_sweep.py: worst per-image
+# |delta| 0.13 dB for bf16 + bf16, 0.052 dB for the default bf16 + f16 pairing), and the error has two sources that touch
+# 1/64 of the arithmetic: the DepthNet's depth (it moves a ray's whole sampling window) and sigma of the LAST sample of a
+# ray, which the reference composites with dist = 1e10 (alpha = step(sigma), sampling_trainer.py:176-180).  With the guard
+# on, the DepthNet runs on split-fp16 operands ("f16x3", fp32-grade) and that one sample per ray is evaluated a second time
+# through an "f16x3" packing of the field (ns_render_args::nerf_guard); the other N - 1 samples keep the fast path.
+_psnr_guard = False
+
+
+def set_psnr_guard(on: bool) -> None:
+    global _psnr_guard
+    _psnr_guard = bool(on)
+
+
+def psnr_guard() -> bool:
+    return _psnr_guard
+
+
+def psnr_guard_handles(depth_net, nerf):
+    """(DepthNet handle, field handle, guard handle or None) for the current compute dtype and guard setting: what the
+    one-call renderers take.  ``depth_net`` / ``nerf``: this package's DepthNet / NeRF modules."""
+    dn, nf = depth_net.packed(), nerf.packed()
+    guard = nerf.packed("f16x3") if (_psnr_guard and nf.dtype in ("bf16", "f16")) else None
+    return dn, nf, guard
 
 
 def _dev(t: Tensor, name: str) -> Tensor:
@@ -411,13 +440,22 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
                          n_samples: int, mode: str, std: float, noise: Optional[Tensor] = None,
                          near: float = 2.0, far: float = 6.0, sphere_radius: float = 2.0,
                          white_bkgd: bool = True, extras: bool = False, workspace: Optional[RenderWorkspace] = None,
-                         device="cuda", mlp_events=None, shard: Optional[Tensor] = None):
+                         device="cuda", mlp_events=None, shard: Optional[Tensor] = None,
+                         one_kernel: Optional[bool] = None, guard: Optional[PackedWeights] = None):
     """DepthNet -> placement -> NeRF MLP -> compositing as one C call.
 
     rays = (o, d, viewdirs) device tensors, or camera = (H, W, K, c2w, row0, row1) to generate
     the rays on the device.  Returns dict(rgb [R,3], disp [R], and with extras z/weights/pts).
     ``shard``: a contiguous fp32 [>= R, 4] device tensor; the compositing kernel then writes (r, g, b, disp) of ray i
     straight into shard[i] (the unit parallel.FrameRenderer all-gathers) and rgb / disp are returned as views of it.
+    ``one_kernel``: None (default) = ns_render_rays_fused -- placement, MLP and compositing in ONE persistent kernel, per-sample
+    data never in HBM -- whenever the configuration supports it (uniform placement, bf16 / f16 field, n_samples a power of
+    two <= 64), else the five-launch chain ns_render_rays_depthnet; True = require it; False = the chain.  Both produce the
+    same bits.
+    ``guard``: the SAME radiance field packed "f16x3" (fp32-grade).  The last sample of every ray -- the one the reference
+    composites with dist = 1e10, so that alpha = step(sigma) -- is then evaluated a second time through it and its sigma
+    replaces the 16-bit one (R of the R * N samples; uniform placement only).  Pair it with an "f16x3" DepthNet handle:
+    the two together are the PSNR guard of the 16-bit paths (see psnr_guard_handles).
     """
     lib = _lib.load()
     a = _lib.RenderArgs()
@@ -455,7 +493,12 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
         keep.append(noise)
         a.noise_dev = noise.data_ptr()
     a.near_, a.far_, a.sphere_radius, a.white_bkgd = float(near), float(far), float(sphere_radius), int(bool(white_bkgd))
-    nbytes = int(lib.ns_render_workspace_bytes(R, N))
+    fused_ok = bool(lib.ns_render_fused_supported(nerf.handle, a.mode, N)) and noise is None
+    if one_kernel and not fused_ok:
+        raise NotImplementedError(f"the one-kernel renderer needs uniform placement, a bf16 / f16 field with view directions and "
+                                  f"n_samples a power of two in [2, 64] (mode {mode!r}, n_samples {N}, dtype {getattr(nerf, 'dtype', '?')})")
+    use_fused = fused_ok if one_kernel is None else bool(one_kernel)
+    nbytes = int(lib.ns_render_fused_workspace_bytes(R) if use_fused else lib.ns_render_workspace_bytes(R, N))
     ws = (workspace or _default_ws).get(nbytes, device)
     base = ws.data_ptr()
     a.workspace_dev = (base + 255) & ~255
@@ -469,7 +512,12 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
         a.weights_dev = out["weights"].data_ptr() if N > 1 else None
     if mlp_events is not None:
         a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
-    check(lib.ns_render_rays_depthnet(C.byref(a), _stream(device)), "ns_render_rays_depthnet")
+    if guard is not None:
+        a.nerf_guard = guard.handle
+    if use_fused:
+        check(lib.ns_render_rays_fused(C.byref(a), _stream(device)), "ns_render_rays_fused")
+    else:
+        check(lib.ns_render_rays_depthnet(C.byref(a), _stream(device)), "ns_render_rays_depthnet")
     return out
 
 
@@ -478,9 +526,10 @@ def render_rays_hierarchical(coarse: PackedWeights, fine: Optional[PackedWeights
                              white_bkgd: bool = True, near: float = 2.0, far: float = 6.0,
                              t_rand: Optional[Tensor] = None, u: Optional[Tensor] = None, extras: bool = False,
                              workspace: Optional[RenderWorkspace] = None, device="cuda", mlp_events=None,
-                             shard: Optional[Tensor] = None):
+                             shard: Optional[Tensor] = None, coarse_events=None):
     """Vanilla coarse + fine pass (sample_as_in_NeRF) as one C call; returns the FINE pass outputs.
-    ``shard``: as in render_rays_depthnet."""
+    ``shard``: as in render_rays_depthnet.  ``mlp_events`` / ``coarse_events``: (begin, end) ops.Event pairs recorded around
+    the fine-pass / coarse-pass MLP kernel."""
     lib = _lib.load()
     a = _lib.HierArgs()
     a.coarse = coarse.handle
@@ -521,8 +570,28 @@ def render_rays_hierarchical(coarse: PackedWeights, fine: Optional[PackedWeights
         a.z_dev, a.weights_dev, a.raw_dev = out["z"].data_ptr(), out["weights"].data_ptr(), out["raw"].data_ptr()
     if mlp_events is not None:
         a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
+    if coarse_events is not None:
+        a.ev_coarse_begin, a.ev_coarse_end = coarse_events[0].handle, coarse_events[1].handle
     check(lib.ns_render_rays_hierarchical(C.byref(a), _stream(device)), "ns_render_rays_hierarchical")
     return out
+
+
+class debug_switch:
+    """Context manager around ns_debug_set: ``with ops.debug_switch(generic_kernels=1, prod_tiles=4): ...`` (tests compare the
+    kernel variants inside one process); every switch is reset to 0 (= the dispatcher's own choice) on exit."""
+
+    def __init__(self, **switches):
+        self.switches = switches
+
+    def __enter__(self):
+        for k, v in self.switches.items():
+            check(_lib.load().ns_debug_set(k.encode(), int(v)), "ns_debug_set")
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.switches:
+            check(_lib.load().ns_debug_set(k.encode(), 0), "ns_debug_set")
+        return False
 
 
 class Event:

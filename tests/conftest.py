@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _reset_process_wide_switches():
+    """The compute dtype and the PSNR guard are process-wide settings (the CLIs set them): no test inherits another's."""
+    yield
+    if "nerf_sampling_amd.ops" in sys.modules:
+        ops = sys.modules["nerf_sampling_amd.ops"]
+        ops.set_psnr_guard(False)
+        ops.set_compute_dtype("f32")
+
+
 @pytest.fixture(scope="session")
 def golden():
     """Loader for the committed fixtures captured from the reference (tools/make_golden.py)."""

@@ -293,10 +293,10 @@ def test_nerf_mlp_16bit(ops, gpu_modules, golden, scene, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3"])
-def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules, dtype, monkeypatch):
+def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules, dtype):
     """The production network (8 x 256, skips = [4]) takes the kernel whose hidden layers are the generated asm streams
-    (csrc/ns_ob16_asm.inc, tools/gen_ob16_asm.py); NS_OB16_GENERIC=1 sends the same call through the compiler-scheduled
-    kernel.  Both issue the same MFMAs in the same order per accumulator, so raw must agree BIT FOR BIT -- a hazard or a
+    (csrc/ns_ob16_asm.inc, tools/gen_ob16_asm.py); the diagnostic switch generic_kernels (ns_debug_set) sends the same call
+    through the compiler-scheduled kernel.  Both issue the same MFMAs in the same order per accumulator, so raw must agree BIT FOR BIT -- a hazard or a
     wrong register in the hand-written stream shows here.  Ragged counts, several groups per workgroup, both input forms."""
     m = gpu_modules("lego_synth")
     net = m["fine"]
@@ -306,27 +306,46 @@ def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_m
     for R, N in ((1, 1), (5, 7), (300, 64), (4100, 64), (2500, 192)):
         pts = ((torch.rand(R, N, 3, generator=gen) * 2 - 1) * 2.5).cuda()
         view = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1).cuda()
-        monkeypatch.setenv("NS_OB16_GENERIC", "1")
-        ref = ops.nerf_forward(packed, pts, view)
-        torch.cuda.synchronize()
-        monkeypatch.delenv("NS_OB16_GENERIC")
-        # the 16-bit production kernel exists with four and with five tiles per wave (chosen per launch; NS_OB16_TILES forces
-        # one): a sample's arithmetic does not depend on the tile it rides in, so both must give the same bits
-        for tiles in (("4", "5", None) if dtype != "f16x3" else (None,)):
-            if tiles is None:
-                monkeypatch.delenv("NS_OB16_TILES", raising=False)
-            else:
-                monkeypatch.setenv("NS_OB16_TILES", tiles)
-            for _ in range(2):      # twice: the ring phase at the start of a launch does not depend on the previous one
-                got = ops.nerf_forward(packed, pts, view)
-                torch.cuda.synchronize()
-                assert torch.isfinite(got).all()
-                assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, tiles, R, N, (got - ref).abs().max().item())
-        monkeypatch.delenv("NS_OB16_TILES", raising=False)
+        with ops.debug_switch(generic_kernels=1):
+            ref = ops.nerf_forward(packed, pts, view)
+            torch.cuda.synchronize()
+        # the 16-bit production kernel exists with four and with five tiles per wave (chosen per launch; the switch
+        # prod_tiles forces one): a sample's arithmetic does not depend on the tile it rides in, so both must give the same bits
+        for tiles in ((4, 5, 0) if dtype != "f16x3" else (0,)):
+            with ops.debug_switch(prod_tiles=tiles):
+                for _ in range(2):      # twice: the ring phase at the start of a launch does not depend on the previous one
+                    got = ops.nerf_forward(packed, pts, view)
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(got).all()
+                    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, tiles, R, N, (got - ref).abs().max().item())
+
+
+def test_depthnet_generated_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules):
+    """The production DepthNet (10 x 256 trunk, fp16 operands -- what the bf16 compute dtype pairs the field with) runs its ten
+    LeakyReLU layers as generated streams (tools/gen_ob16_asm.py, act = "leaky"); the switch generic_kernels sends the same
+    call through the compiled layers, which apply the same packed v_pk_mul_f16 / v_pk_max_f16 LeakyReLU: depths must agree bit
+    for bit.  Ragged ray counts, several groups per workgroup; rays that miss the sphere (NaN) included."""
+    m = gpu_modules("lego_synth")
+    dn = m["depth"]
+    assert list(dn.cat_hidden_sizes) == [256] * 10
+    packed = dn.packed("f16")
+    gen = torch.Generator().manual_seed(17)
+    for R in (1, 77, 4096, 70001):
+        o = (torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1) * 4.0).cuda()
+        d = (-o / 4.0 + 0.25 * torch.randn(R, 3, generator=gen).cuda()).contiguous()
+        with ops.debug_switch(generic_kernels=1):
+            ref = ops.depthnet_forward(packed, o, d)
+            torch.cuda.synchronize()
+        for _ in range(2):
+            got = ops.depthnet_forward(packed, o, d)
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (R, (got - ref).abs().nan_to_num().max().item())
+        hit = torch.isfinite(ref)
+        assert hit.float().mean() > 0.3 and bool(((ref[hit] >= 2.0) & (ref[hit] <= 6.0)).all())
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3"])
-def test_hand_scheduled_layers_other_input_forms(ops, gpu_modules, dtype, monkeypatch):
+def test_hand_scheduled_layers_other_input_forms(ops, gpu_modules, dtype):
     """The same bit-for-bit comparison for the other two input forms of the production kernels: rays (o, d, z) with the
     points formed in-kernel -- what the frame renderer launches -- and the pre-embedded [M, 90] rows of NeRF.forward
     (their own kernel instantiations, four and five tiles)."""
@@ -344,19 +363,16 @@ def test_hand_scheduled_layers_other_input_forms(ops, gpu_modules, dtype, monkey
     def both():
         return ops.nerf_forward_rays(packed, o, d, z, view), ops.nerf_forward_embedded(packed, x90)
 
-    monkeypatch.setenv("NS_OB16_GENERIC", "1")
-    ref = both()
-    torch.cuda.synchronize()
-    monkeypatch.delenv("NS_OB16_GENERIC")
-    for tiles in (("4", "5") if dtype != "f16x3" else (None,)):
-        if tiles is not None:
-            monkeypatch.setenv("NS_OB16_TILES", tiles)
-        got = both()
+    with ops.debug_switch(generic_kernels=1):
+        ref = both()
         torch.cuda.synchronize()
+    for tiles in ((4, 5) if dtype != "f16x3" else (0,)):
+        with ops.debug_switch(prod_tiles=tiles):
+            got = both()
+            torch.cuda.synchronize()
         for a, b in zip(got, ref):
             assert torch.isfinite(a).all()
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (dtype, tiles, (a - b).abs().max().item())
-    monkeypatch.delenv("NS_OB16_TILES", raising=False)
 
 
 @pytest.mark.parametrize("D,W,skip", [(2, 128, -1), (3, 256, 0), (5, 128, 3), (6, 256, 4), (7, 128, 1), (8, 256, -1), (9, 256, 4)])

@@ -117,7 +117,7 @@ def test_production_kernel_is_straight_line_hand_scheduled_code(nerf16_isa):
             seg = seg[:next(n for n, i in enumerate(seg) if i.startswith("s_mov_b32 m0,")) + 1]
         mfmas.append(sum("v_mfma" in i for i in seg))
         copies = sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg)
-        assert copies <= 12, (a, b, copies)
+        assert copies <= 16, (a, b, copies)      # (a full activation set would be 128)
         # what the statements themselves need: one v_accvgpr_write per dword written to set A, none in the A -> V layers
         w = sum(i.startswith("v_accvgpr_write") for i in seg)
         assert min(abs(w - k) for k in (0, 64, 128)) <= 8, (a, b, w)
@@ -156,8 +156,8 @@ def test_five_tile_production_kernel_keeps_scratch_out_of_the_layers():
         for a, b in zip(starts, starts[1:]):
             seg = ins[a:b]
             assert sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg) <= 24   # (a full set is 160)
-            w = sum(i.startswith("v_accvgpr_write") for i in seg)      # a statement's own AGPR writes (+ a few strays)
-            assert min(abs(w - k) for k in (0, 80, 160)) <= 8, w
+            w = sum(i.startswith("v_accvgpr_write") for i in seg)      # a statement's own AGPR writes (+ a few strays: the
+            assert min(abs(w - k) for k in (0, 80, 160)) <= 12, w         # compiler parks single values in the free a[200:255])
 
 
 def _check_mlp_kernels(dis, notes, name_part, n_expected, mfma_pat, min_mfma):
@@ -178,7 +178,30 @@ def test_depthnet16_kernels_use_no_scratch_and_no_full_dma_wait():
     """The folded DepthNet on the same engine: bf16, f16 and split-f16 (f16x3), W = 256 and 128 -- no scratch (round 1's
     kernel spilled 91 VGPRs and kept a 655 MB global stash), no compiler-inserted full DMA wait in the slab loop."""
     dis, notes = _isa_of(b"depthnet_ob16_kernel")
-    _check_mlp_kernels(dis, notes, "depthnet_ob16_kernel", 6, "v_mfma_f32_16x16x32", 500)
+    _check_mlp_kernels(dis, notes, "depthnet_ob16_kernel", 7, "v_mfma_f32_16x16x32", 500)
+
+
+def test_depthnet_production_kernel_is_straight_line_generated_code():
+    """The production DepthNet (ten 8-K-block -> 256 LeakyReLU layers after the fold, fp16 operands): every layer is one
+    generated statement (tools/gen_ob16_asm.py, act = "leaky"), 512 MFMAs each, the 1-row head is the only compiled layer;
+    between the statements the compiler moves no activation set (a copy would be 128 v_accvgpr / v_mov per layer) and the
+    kernel uses no scratch."""
+    dis, notes = _isa_of(b"depthnet_ob16_kernel")
+    fns = {k: v for k, v in _functions(dis).items() if re.search(r"Mma16F16EEELi8ELb1EEE", k)}
+    assert len(fns) == 1, sorted(_functions(dis))
+    ins = [i.split("//")[0].strip() for i in next(iter(fns.values()))]
+    assert not any(i.startswith("scratch_") for i in ins)
+    assert sum("v_mfma_f32_16x16x32_f16" in i for i in ins) == 10 * 512 + 32
+    starts = [n for n, i in enumerate(ins) if re.match(r"ds_read_b128 v\[48:51\], v\d+$", i)]
+    assert len(starts) == 10, starts
+    for a, b in zip(starts, starts[1:]):
+        seg = ins[a:b]
+        assert sum("v_mfma" in i for i in seg) == 512
+        assert sum(i.startswith("v_pk_mul_f16") for i in seg) == 128 and sum(i.startswith("v_pk_max_f16") for i in seg) == 128
+        assert sum(i.startswith(("v_accvgpr_mov", "v_mov_b32", "v_mov_b64", "v_accvgpr_read")) for i in seg) <= 12
+        w = sum(i.startswith("v_accvgpr_write") for i in seg)      # V -> A layers write set A one dword at a time
+        assert min(abs(w - k) for k in (0, 128)) <= 8, w
+        assert sum(i.startswith("s_nop") for i in seg) <= 12
 
 
 def test_nerf_x3_kernels_use_no_scratch_and_no_full_dma_wait():
