@@ -4,9 +4,14 @@
 // plain MLP:  cat[gamma(o), gamma(d), gamma(sphere intersections)] (8 K-blocks) -> W, LeakyReLU -> ... -> 1, sigmoid.
 // A wave owns T = 4 tiles of 16 rays (T = 2 with split "f16x3" operands, the fp32-grade path on the same engine);
 // activations never leave the register file; no global scratch, no spills.  HBM traffic per ray: 24 B in, 4 B out.
+// The production shape (10 x 256 trunk, fp16 operands: what the bf16 compute dtype pairs the field with) runs its ten
+// 256 x 256 LeakyReLU layers -- the folded input layer has the same 8 K-blocks -- as generated instruction streams
+// (tools/gen_ob16_asm.py, act = "leaky"; PROD below), like the radiance-field kernel's hidden layers.
 #include "ns_common.h"
 #include "ns_mlp_engine.h"
 #include "ns_weights.h"
+
+#include "ns_ob16_asm.inc"
 
 namespace {
 
@@ -54,7 +59,9 @@ struct Depth16Args {
   float* z;
 };
 
-template <class E, int NKB>   // E: engine policy; NKB = W / 32 K-blocks of a hidden layer
+// PROD: ten layers of 8 K-blocks -> 256 (the production DepthNet after the fold) as straight-line code, every layer a
+// generated statement: the embedding is set V (v[128:255]), layers alternate V -> A -> V, the head reads set V.
+template <class E, int NKB, bool PROD = false>   // E: engine policy; NKB = W / 32 K-blocks of a hidden layer
 __global__ void __launch_bounds__(kWaves * 64)
 depthnet_ob16_kernel(Depth16Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,6 +147,32 @@ depthnet_ob16_kernel(Depth16Args a) {
     auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
 
+    if constexpr (PROD) {
+      static_assert(T == 4 && NKB == 8 && kInKB == 8 && NWAVES == 4, "the generated streams are W = 256, four tiles, four waves");
+      prefetch(grp + gridDim.x);   // before the first statement: compiled code between two statements costs register copies
+      u32x4 A[8 * T], V[8 * T];
+      static_for<T>([&](auto t_) {
+        static_for<kInKB>([&](auto kb_) {
+          V[8 * decltype(t_)::value + decltype(kb_)::value] = __builtin_bit_cast(u32x4, e[decltype(t_)::value][decltype(kb_)::value].v);
+        });
+      });
+      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 0 (folded input layer): V -> A
+      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 1: A -> V
+      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 2
+      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 3
+      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 4
+      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 5
+      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 6
+      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 7
+      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 8
+      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 9: the trunk's output is set V
+      static_for<T>([&](auto t_) {
+        static_for<NKB>([&](auto kb_) {
+          hB[decltype(t_)::value][decltype(kb_)::value].v = __builtin_bit_cast(typename M::AFrag, V[8 * decltype(t_)::value + decltype(kb_)::value]);
+        });
+      });
+      E::template layer<1, NKB, kNone>(ring, bias, g, hA, last, in_B);
+    } else {
     // layer 0 (folded): e -> hA
     E::template layer<NSB, kInKB, kLeaky>(ring, bias, g, hA, last, in_e);
     E::template convert_last<kLeaky, NSB>(hA, last); bias += NSB * 16;
@@ -158,6 +191,7 @@ depthnet_ob16_kernel(Depth16Args a) {
     }
     // head (W -> 1): row 0 of a 16-row sub-block (lane group 0, register 0), sigmoid, z = near (1 - s) + far s
     E::template layer<1, NKB, kNone>(ring, bias, g, hB, last, in_A);
+    }
     if (g == 0) {
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
@@ -177,7 +211,7 @@ int depth16_program_slabs(int W, int n_layers, int cpk) {   // cpk: stream chunk
          ob16_layer_slabs(1, cpk * NKB, dp);
 }
 
-template <class E, int NKB>
+template <class E, int NKB, bool PROD = false>
 int launch(Depth16Args& a, hipStream_t stream) {
   using M = typename E::M;
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
@@ -186,7 +220,7 @@ int launch(Depth16Args& a, hipStream_t stream) {
     ns::set_error("ns_depthnet_forward: %zu bytes of LDS needed (too many layers for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
   }
-  auto kern = depthnet_ob16_kernel<E, NKB>;
+  auto kern = depthnet_ob16_kernel<E, NKB, PROD>;
   NS_HIP(ns::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds));
   const int64_t n_tiles = (a.R + 15) / 16;
   const int64_t n_groups = (n_tiles + kWaves * E::T - 1) / (kWaves * E::T);
@@ -216,7 +250,11 @@ int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const fl
   a.near_ = near_; a.far_ = far_; a.radius = sphere_radius; a.z = z_dev;
   const bool wide = net->width == 256;
   if (net->dtype == NS_DTYPE_BF16) return wide ? launch<Plain16<Mma16BF16>, 8>(a, stream) : launch<Plain16<Mma16BF16>, 4>(a, stream);
-  if (net->dtype == NS_DTYPE_F16) return wide ? launch<Plain16<Mma16F16>, 8>(a, stream) : launch<Plain16<Mma16F16>, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_F16) {
+    if (wide && net->depth == 10 && !ns::debug_flags().generic_kernels)      // the production trunk: generated layer streams
+      return launch<Plain16<Mma16F16>, 8, true>(a, stream);
+    return wide ? launch<Plain16<Mma16F16>, 8>(a, stream) : launch<Plain16<Mma16F16>, 4>(a, stream);
+  }
   if (net->dtype == NS_DTYPE_F16X3) return wide ? launch<Split16, 8>(a, stream) : launch<Split16, 4>(a, stream);
   return NS_E_UNSUPPORTED;
 }

@@ -717,6 +717,7 @@ constexpr int kOb16Ahead = NS_OB16_AHEAD;   // weight slabs in flight ahead of t
 
 struct Mma16BF16 {
   static constexpr int kDtype = 1;
+  static constexpr bool kPackedLeaky = false;     // (gfx950 has no packed bf16 multiply / max: LeakyReLU runs on the fp32 values)
   using AFrag = bf16x8;
   struct Block { bf16x8 v; };                       // one lane's 8 features of a 32-feature K-block
   template <bool RELU>
@@ -735,6 +736,17 @@ struct Mma16BF16 {
 };
 struct Mma16F16 {
   static constexpr int kDtype = 2;
+  // LeakyReLU(0.01) of a converted pair on the PACKED fp16 values, max(x, 0.01 x) as v_pk_mul_f16 + v_pk_max_f16: two VALU
+  // instructions per pair instead of four on the fp32 values, and exactly what the generated DepthNet layers issue
+  // (tools/gen_ob16_asm.py, act = "leaky"), so compiled and generated layers agree bit for bit.  0.01 is 0x211f in fp16
+  // (0.0100021): the slope of the negative branch carries a 2e-4 relative error, below fp16's own rounding of the result.
+  static constexpr bool kPackedLeaky = true;
+  __device__ static __forceinline__ uint32_t leaky2(uint32_t w) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 x = __builtin_bit_cast(h2, w);
+    const h2 k = {static_cast<_Float16>(0.01f), static_cast<_Float16>(0.01f)};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(x, x * k));
+  }
   using AFrag = f16x8;
   struct Block { f16x8 v; };
   template <bool RELU>
@@ -769,6 +781,11 @@ __device__ __forceinline__ void convert_piece16(typename M::Block& out, const f3
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w = __builtin_bit_cast(u32x4, out.v);
   float a = c[2 * J], b = c[2 * J + 1];
+  if constexpr (ACT == kLeaky && M::kPackedLeaky) {
+    w[2 * (SB & 1) + J] = M::leaky2(M::template pack2<false>(a, b));
+    out.v = __builtin_bit_cast(typename M::AFrag, w);
+    return;
+  }
   if constexpr (ACT == kLeaky) {
     a = __builtin_fmaxf(a, 0.01f * a);
     b = __builtin_fmaxf(b, 0.01f * b);

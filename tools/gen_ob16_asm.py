@@ -293,8 +293,11 @@ def issue_cycles(ins):
     return c
 
 
-def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
-    """One hidden layer, ReLU: set A -> set V (in_a) or set V -> set A; skip: K-blocks 0, 1 are the embedded point.
+def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8, act="relu"):
+    """One hidden layer: set A -> set V (in_a) or set V -> set A; skip: K-blocks 0, 1 are the embedded point.
+    act = "relu" (the radiance field: a packed signed-16-bit max after the conversion) or "leaky" (the DepthNet's
+    LeakyReLU(0.01), fp16 only, on the PACKED value: v_pk_mul_f16 by 0.01, v_pk_max_f16 -- one more pipeline stage, issued
+    in G0 / G1 of the step after the conversion; the compiled layer applies the same two packed operations).
 
     A chunk step is  [wait] M0 <G0> M1 <G1> M2 <G2> M3 <G3>  (M = the four tiles' MFMAs of one A fragment).  What rides in
     the gaps: G1 the fragment read three chunks ahead; the conversion of the previous sub-block, one dword per step, as a
@@ -310,6 +313,9 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
     IN = m.SETA if in_a else m.SETV
     OUT = m.SETV if in_a else m.SETA
     cvt = "v_cvt_pk_bf16_f32" if dt == "bf16" else "v_cvt_pk_f16_f32"
+    leaky = act == "leaky"
+    assert act in ("relu", "leaky") and not (leaky and (dt != "f16" or T != 4 or skip)), "LeakyReLU streams: fp16, four tiles"
+    TMP2 = R('v', 55)                    # the scaled copy of the piece in flight (Map4: v55 is free)
     e = Emitter(dt)
     e.salu("s_mov_b32 %[keep], m0")
     e.lds_read(BIAS, "%[bias]", 0)
@@ -331,12 +337,16 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
         lo, hi, _ = piece_regs(s, piece)
         e.valu(f"{cvt} {fmt(tmp)}, {fmt(lo)}, {fmt(hi)}", (lo, hi), (tmp,))
 
+    def op_scale(s, piece, tmp):         # LeakyReLU only: 0.01 x, packed
+        e.valu(f"v_pk_mul_f16 {fmt(TMP2)}, {fmt(tmp)}, %[slope]", (tmp,), (TMP2,))
+
     def op_max(s, piece, tmp):
         dword = piece_regs(s, piece)[2]
-        if in_a:
-            e.valu(f"v_pk_max_i16 {fmt(dword)}, {fmt(tmp)}, 0", (tmp,), (dword,))
+        dst = dword if in_a else tmp
+        if leaky:
+            e.valu(f"v_pk_max_f16 {fmt(dst)}, {fmt(tmp)}, {fmt(TMP2)}", (tmp, TMP2), (dst,))
         else:
-            e.valu(f"v_pk_max_i16 {fmt(tmp)}, {fmt(tmp)}, 0", (tmp,), (tmp,))
+            e.valu(f"v_pk_max_i16 {fmt(dst)}, {fmt(tmp)}, 0", (tmp,), (dst,))
 
     def op_accw(s, piece, tmp):
         if not in_a:
@@ -364,6 +374,10 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
         def mm(t):
             e.mfma(ACC(par, t), frag, operand(t), BIAS if kc == 0 else ACC(par, t))
 
+        def g_scale():
+            if leaky and max_q and not OPT.no_conv:
+                op_scale(*max_q[0])
+
         def g_max():
             if max_q and not OPT.no_conv:
                 op_max(*max_q[0])
@@ -378,10 +392,15 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
         if c == 0 and not OPT.no_barrier:
             e.salu(f"s_waitcnt vmcnt({VM_WAIT})")
             e.salu("s_barrier")
-        g_max()
+        if leaky:
+            g_scale()
+        else:
+            g_max()
         mm(1)
         # ---- G1
         g_read()
+        if leaky:
+            g_max()
         mm(2)
         # ---- G2
         if sb > 0 and kc < n_main and not OPT.no_conv:
@@ -421,6 +440,8 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
     # parity's accumulators are free), stage by stage
     if not OPT.no_conv:
         for it in max_q:
+            if leaky:
+                op_scale(*it)
             op_max(*it)
         for it in accw_q + max_q:
             op_accw(*it)
@@ -431,6 +452,8 @@ def gen_layer(dt, in_a, skip, m=None, nsb=16, nkb_h=8):
             for piece in pcs:
                 op_cvt(s, piece, scratch[piece])
             for piece in pcs:
+                if leaky:
+                    op_scale(s, piece, scratch[piece])
                 op_max(s, piece, scratch[piece])
             for piece in pcs:
                 op_accw(s, piece, scratch[piece])
@@ -929,7 +952,7 @@ def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
     return e, slabs
 
 
-def cpp_function(name, dt, in_a, skip, e, slabs, mp=None):
+def cpp_function(name, dt, in_a, skip, e, slabs, mp=None, leaky=False):
     mp = mp or Map4
     nt = mp.T
     m = {"bf16": "Mma16BF16", "f16": "Mma16F16", "f16x3": "Mma16F16x3"}[dt]
@@ -956,6 +979,26 @@ def cpp_function(name, dt, in_a, skip, e, slabs, mp=None):
     clob = ['"memory"', '"scc"', '"vcc"'] + [f'"v{i}"' for i in mp.CLOBBER]
     n_mfma = sum(i.kind == "mfma" for i in e.ins)
     cyc = issue_cycles(e.ins)
+    if leaky:
+        assert not skip and nt == 4
+        ins.append('[slope] "s"(slope)')
+        return f"""
+// {name}: {len(e.ins)} instructions, {n_mfma} MFMAs, {slabs} slabs; issue-port estimate {cyc} cycles = {cyc / slabs:.0f} per slab
+// (matrix pipe: {16 * n_mfma / slabs:.0f}); s_nop {sum(i.kind == 'nop' for i in e.ins)}, s_waitcnt {sum(i.kind == 'wait' for i in e.ins)}
+template <> struct HiddenLeakyAsm<{m}, {nt}, {'true' if in_a else 'false'}> {{
+  static constexpr int kSlabs = {slabs};
+  static __device__ __forceinline__ void run(u32x4 (&A)[{8 * nt}], u32x4 (&V)[{8 * nt}], u32x4 (&F)[4],
+                                             uint32_t rb0, uint32_t rb1, uint32_t rb2, uint32_t rb3, uint32_t bias, uint32_t loff,
+                                             uint64_t sbase, uint32_t nsl, uint32_t ldsw, uint32_t& islab, uint32_t& dsto, uint32_t slope) {{
+    uint32_t keep;
+    asm volatile(
+      "{text}"
+      : {', '.join(outs)}
+      : {', '.join(ins)}
+      : {', '.join(clob)});
+  }}
+}};
+"""
     return f"""
 // {name}: {len(e.ins)} instructions, {n_mfma} MFMAs, {slabs} slabs; issue-port estimate {cyc} cycles = {cyc / slabs:.0f} per slab
 // (matrix pipe: {16 * n_mfma / slabs:.0f}); s_nop {sum(i.kind == 'nop' for i in e.ins)}, s_waitcnt {sum(i.kind == 'wait' for i in e.ins)}
@@ -985,6 +1028,7 @@ struct Mma16F16;
 struct Mma16F16x3;
 template <class M, int NT, bool IN_A, bool SKIP> struct HiddenAsm;   // NT: tiles of 8 K-block tuples per activation set
 template <class M, int NT, int KIND> struct SpecialAsm;             // KIND: 0 layer 0, 1 view layer, 2 rgb head
+template <class M, int NT, bool IN_A> struct HiddenLeakyAsm;        // the DepthNet's hidden layers: LeakyReLU(0.01), fp16
 """
 
 
@@ -1032,6 +1076,15 @@ __device__ __forceinline__ void hidden_asm_run(PipeT& ring, const float* bias_ld
   AsmRingArgs r;
   asm_ring_begin(ring, bias_lds, g, r);
   Gen::run(A, V, X, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto);
+  asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
+}
+// one hidden layer of the DepthNet (LeakyReLU(0.01) on the packed fp16 values): set A -> set V or back
+template <class M, int NT, bool IN_A, class PipeT>
+__device__ __forceinline__ void hidden_leaky_asm_run(PipeT& ring, const float* bias_lds, int g, u32x4 (&A)[8 * NT], u32x4 (&V)[8 * NT]) {
+  using Gen = HiddenLeakyAsm<M, NT, IN_A>;
+  AsmRingArgs r;
+  asm_ring_begin(ring, bias_lds, g, r);
+  Gen::run(A, V, r.F, r.rb0, r.rb1, r.rb2, r.rb3, r.bias, r.loff, r.sbase, r.nsl, r.ldsw, r.islab, r.dsto, 0x211f211fu);   // 0.01 as packed fp16
   asm_ring_end<typename M::AFrag>(ring, r, Gen::kSlabs);
 }
 // layer 0: the embedded point X -> set A
@@ -1105,6 +1158,12 @@ def main():
             for kind in ("layer0", "views", "rgb"):
                 e, slabs = gen_layer_special(dt, kind, mp)
                 out.append(cpp_special(dt, kind, e, slabs, mp))
+    for in_a in (True, False):           # the DepthNet's hidden layers (fp16 operands, four tiles)
+        e, slabs = gen_layer("f16", in_a, False, act="leaky")
+        name = f"f16 LeakyReLU {'A->V' if in_a else 'V->A'}"
+        out.append(cpp_function(name, "f16", in_a, False, e, slabs, leaky=True))
+        print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 1024), "
+              f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
     for in_a in (True, False):
         for skip in (False, True):
             e, slabs = gen_layer_x3(in_a, skip)
