@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--other-configs", dest="other_configs", action="store_true", default=True,
                     help="also run f16x3 / f32 at the headline shape, configs[2] (vanilla 64+128) and the configs[4] shape")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false")
+    ap.add_argument("--chain", action="store_true", help="render with the five-launch chain (ns_render_rays_depthnet) instead of "
+                    "the one-kernel renderer (ns_render_rays_fused): same bits, for A/B timing")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a one-GPU box, all ranks sharing cuda:0)")
     return ap.parse_args(argv)
@@ -249,6 +251,19 @@ def cpu_baseline(params, H, W, K, c2w, n_samples, rows, budget_s=24.0):
                       f"reference's chunks (32768 rays / 65536 MLP rows), {dt:.1f} s"}, ref
 
 
+def step_rule_mask(O, raw, z, d, rgb_ref, eps):
+    """Rays whose ORACLE colour moves by > 1e-2 when sigma of the LAST sample alone moves by +-eps: the reference composites
+    that sample with dist = 1e10 (sampling_trainer.py:176-180), alpha_last = step(sigma_last), so colour is discontinuous in
+    sigma_last wherever transmittance is left."""
+    ill = torch.zeros(raw.shape[0], dtype=torch.bool)
+    with torch.no_grad():
+        for sgn in (-1.0, 1.0):
+            pert = raw.clone()
+            pert[:, -1, 3] += sgn * eps
+            ill |= (O.raw2outputs(pert, z, d, 0.0, True)[0] - rgb_ref).abs().max(-1).values > 1e-2
+    return ill
+
+
 def accuracy_vs_oracle(ops, depth_w, nerf_w, ref, H, W, K, c2w, n_samples, dtype, device, pose_k, scene):
     """Second half of the cpu_baseline leg (the oracle as CHECKER, outside the timed region, rank 0 at N = 1 only).
 
@@ -283,12 +298,13 @@ def accuracy_vs_oracle(ops, depth_w, nerf_w, ref, H, W, K, c2w, n_samples, dtype
         fix = raw_hip.clone()
         fix[:, -1, 3] = raw[:, -1, 3]
         rgb_fix = O.raw2outputs(fix, z, d, 0.0, True)[0]
-        ill = torch.zeros(n, dtype=torch.bool)
-        for sgn in (-1.0, 1.0):
-            pert = raw.clone()
-            pert[:, -1, 3] += sgn * 3.0 * last_rms
-            ill |= (O.raw2outputs(pert, z, d, 0.0, True)[0] - rgb_ref).abs().max(-1).values > 1e-2
+    ill = step_rule_mask(O, raw, z, d, rgb_ref, 3.0 * last_rms)
+    mse_vs_oracle = float(((rgb - rgb_ref) ** 2).mean())
     out.update({
+        # The scene PSNR at which an UNCORRELATED error of this size moves the PSNR by exactly 0.05 dB:
+        # 10 log10(1 + mse_err / mse_scene) = 0.05  <=>  mse_scene = mse_err / 0.01158.  On a scene that renders BELOW this
+        # figure the 0.05 dB bar cannot fail whatever the error looks like; above it, it can.
+        "breakeven_scene_psnr_db": (-10.0 * float(np.log10(mse_vs_oracle / 0.011579))) if mse_vs_oracle > 0 else None,
         "sigma_err_rms_over_max_sigma": float(d_sig.pow(2).mean().sqrt()) / max(sig_max, 1e-30),
         "sigma_last_err_rms": last_rms, "max_abs_sigma": sig_max,
         "psnr_mlp_at_oracle_points_db": psnr(rgb_mlp, rgb_ref),
@@ -313,7 +329,7 @@ def scene_psnr(rgb_build, ref, H, W, K, c2w, dtype):
     p_ref, p_build = psnr(ref["rgb"][:n], gt), psnr(rgb_build, gt)
     return {"ground_truth": "nerf_sampling_amd/analytic_scene.py (exact ray cast)", "rows": [r0, r1],
             "oracle_fp32_db": p_ref, f"build_{dtype}_db": p_build, "delta_db": p_build - p_ref,
-            "within_0.05_db": abs(p_build - p_ref) <= 0.05}
+            "within_0.05_db": abs(p_build - p_ref) <= 0.05, "rays": n}
 
 
 def api_path_rate(coarse, fine, dn, dtype, H, W, K, poses, n_samples, device, frames=6, blocking=False):
@@ -391,19 +407,25 @@ class Timed:
         return float(np.mean([b.elapsed_ms(e) for b, e in self.events])) if self.events else float("nan")
 
 
-def hier_rows_fn(ops, coarse_w, fine_w, H, W, K, device, events, max_events=128):
-    ws, ring = ops.RenderWorkspace(), []
+def hier_rows_fn(ops, coarse_w, fine_w, H, W, K, device, events, max_events=128, coarse_events=None):
+    """``events`` / ``coarse_events``: lists the (begin, end) hipEvent pairs of the fine-pass / coarse-pass MLP kernel of each
+    call are appended to."""
+    ws, ring, cring = ops.RenderWorkspace(), [], []
 
     def rows_fn(c2w, row0, row1, shard=None):
         if not ring:
             ring.extend((ops.Event(), ops.Event()) for _ in range(max_events))
-        ev = None
+            cring.extend((ops.Event(), ops.Event()) for _ in range(max_events if coarse_events is not None else 0))
+        ev = cev = None
         if len(events) < max_events:
             ev = ring[len(events)]
+            if coarse_events is not None:
+                cev = cring[len(events)]
+                coarse_events.append(cev)
             events.append(ev)
         out = ops.render_rays_hierarchical(coarse_w, fine_w, camera=(H, W, K, c2w, row0, row1), n_coarse=64,
                                            n_importance=128, lindisp=True, white_bkgd=True, workspace=ws,
-                                           device=device, mlp_events=ev, shard=shard)
+                                           device=device, mlp_events=ev, shard=shard, coarse_events=cev)
         return out["rgb"], out["disp"]
 
     return rows_fn
@@ -444,16 +466,38 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     # -- f16x3 / f32 (and the other 16-bit type) at configs[1]: error against the band the cpu_baseline leg rendered
     r0, r1 = ref["rows"]
     n = (r1 - r0) * W
-    for dtype, steps in (("f16x3", 4), ("f32", 3), ("f16" if headline_dtype == "bf16" else "bf16", 5)):
-        nw, dw = fine.packed(dtype), dn.packed(ops.depthnet_dtype_for(dtype))
+    from nerf_sampling_amd import analytic_scene
+    gt_band = analytic_scene.frame(H, W, K, poses[pose_k], r0, r1)[0].reshape(-1, 3)
+    # (label, field operands, guarded, timed steps); "guarded" = ops.set_psnr_guard: f16x3 DepthNet + every ray's last sample on f16x3
+    for label, dtype, guarded, steps in ((f"{headline_dtype} + PSNR guard", headline_dtype, True, 5), ("f16x3", "f16x3", False, 4),
+                                         ("f32", "f32", False, 3),
+                                         ("f16" if headline_dtype == "bf16" else "bf16",) * 2 + (False, 5)):
+        nw = fine.packed(dtype)
+        dw = dn.packed("f16x3" if guarded else ops.depthnet_dtype_for(dtype))
+        gw = fine.packed("f16x3") if guarded else None
         events = []
-        t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events), events, device)
+        t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events, guard=gw),
+                  events, device)
         elapsed, _, _ = t.run(poses, steps, 1, sync)
         rl = roofline_block(dtype, t.kernel_ms(), H * W, samples, cfg["D"], cfg["W"], cfg["skip"])
         rgb = ops.render_rays_depthnet(dw, nw, camera=(H, W, K, poses[pose_k], r0, r1), n_samples=samples, mode="uniform",
-                                       std=0.1, device=device)["rgb"].cpu()
+                                       std=0.1, device=device, guard=gw)["rgb"].cpu()
         err = (rgb - ref["rgb"][:n]).abs().max(-1).values
-        out.append({"config": f"configs[1] shape ({H}x{W}, DepthNet + {samples} samples), {dtype}", "dtype": dtype,
+        mse_err = float(((rgb - ref["rgb"][:n]) ** 2).mean())
+        p_ref, p_build = psnr(ref["rgb"][:n], gt_band), psnr(rgb, gt_band)
+        # the same step-rule accounting as the headline: sigma_last error of THIS dtype measured at the oracle's points
+        raw_o, z_o, d_o, o_o, v_o = (ref[k][:n] for k in ("raw", "z", "d", "o", "view"))
+        raw_hip = ops.nerf_forward_rays(nw, o_o.to(device), d_o.to(device), z_o.to(device), v_o.to(device)).cpu()
+        last_rms = float((raw_hip[:, -1, 3] - raw_o[:, -1, 3]).pow(2).mean().sqrt())
+        ill = step_rule_mask(O, raw_o, z_o, d_o, ref["rgb"][:n], 3.0 * last_rms)
+        out.append({"config": f"configs[1] shape ({H}x{W}, DepthNet + {samples} samples), {label}", "dtype": dtype,
+                    "depthnet_operands": dw.dtype, "psnr_guard": guarded,
+                    "scene_psnr": {"oracle_fp32_db": p_ref, "build_db": p_build, "delta_db": p_build - p_ref,
+                                   "within_0.05_db": abs(p_build - p_ref) <= 0.05},
+                    "breakeven_scene_psnr_db": (-10.0 * float(np.log10(mse_err / 0.011579))) if mse_err > 0 else None,
+                    "sigma_last_err_rms": last_rms, "step_rule_frac": float(ill.float().mean()),
+                    "rays_over_1e-4_outside_step_rule": float(((err > 1e-4) & ~ill).float().mean()),
+                    "max_abs_err_outside_step_rule": float(err[~ill].max()) if (~ill).any() else None,
                     "steps": steps, "rays_per_s": H * W * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
                     "kernel_ms": rl["kernel_ms"], "frac": rl["frac"], "executed_mfma_frac": rl["executed_mfma_frac"],
                     "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
@@ -461,11 +505,14 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
                     "psnr_vs_oracle_db": psnr(rgb, ref["rgb"][:n]), "oracle_rays": n})
     # -- configs[2]: vanilla hierarchical 64 + 128, coarse + fine network, headline dtype; oracle on a thin band
     cw, fw = coarse.packed(headline_dtype), fine.packed(headline_dtype)
-    events = []
-    t = Timed(H, W, hier_rows_fn(ops, cw, fw, H, W, K, device, events), events, device)
+    events, cevents = [], []
+    t = Timed(H, W, hier_rows_fn(ops, cw, fw, H, W, K, device, events, coarse_events=cevents), events, device)
     steps = 4
     elapsed, _, _ = t.run(poses, steps, 1, sync)
+    cevents = cevents[-len(events):]                 # the warm-up frame's pair was dropped from `events` by Timed.run
     rl = roofline_block(headline_dtype, t.kernel_ms(), H * W, 192, cfg["D"], cfg["W"], cfg["skip"])
+    coarse_ms = float(np.mean([b.elapsed_ms(e) for b, e in cevents]))
+    rlc = roofline_block(headline_dtype, coarse_ms, H * W, 64, cfg["D"], cfg["W"], cfg["skip"])
     b0 = H // 2
     batch, _, _, _ = O.ray_batch_from_camera(H, W, K, poses[pose_k], 2.0, 6.0)
     with torch.no_grad():
@@ -477,6 +524,10 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
                 "dtype": headline_dtype, "steps": steps, "rays_per_s": H * W * steps / elapsed,
                 "ms_per_step": 1e3 * elapsed / steps, "kernel_ms": rl["kernel_ms"], "kernel": "fine pass (192 samples/ray)",
                 "frac": rl["frac"], "executed_mfma_frac": rl["executed_mfma_frac"],
+                "coarse_pass": {"kernel": "coarse pass (64 samples/ray)", "kernel_ms": coarse_ms, "frac": rlc["frac"],
+                                "executed_mfma_frac": rlc["executed_mfma_frac"],
+                                "effective_frac_on_reference_flops": rlc["effective_frac_on_reference_flops"]},
+                "ms_outside_the_two_mlp_kernels": 1e3 * elapsed / steps - rl["kernel_ms"] - coarse_ms,
                 "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
                 "max_abs_err_vs_oracle": float(err.max()), "median_abs_err_vs_oracle": float(err.median()),
                 "psnr_vs_oracle_db": psnr(got, exp), "oracle_rays": int(exp.shape[0])})
@@ -543,7 +594,8 @@ def main():
     ops.set_compute_dtype("f32")
     events = []
     if args.mode == "depthnet":
-        rows_fn = hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1, device=device, events=events)
+        rows_fn = hip_row_renderer(depth_w, nerf_w, H, W, K, args.samples, "uniform", 0.1, device=device, events=events,
+                                   one_kernel=False if args.chain else None)
         samples_in_timed_kernel = args.samples
     else:
         rows_fn = hier_rows_fn(ops, coarse.packed(args.dtype), nerf_w, H, W, K, device, events)
@@ -568,20 +620,29 @@ def main():
                               fine.D, fine.W, 4)
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (PMC counters cannot
     # be read from inside the process); only quoted for the exact workload and build they were collected on
-    tpath = os.path.join(ROOT, "profiles", "r03c_traffic_nerf_mlp.json")
+    tname = "r04_traffic_nerf_mlp.json"
+    tpath = os.path.join(ROOT, "profiles", tname)
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
-            and os.path.exists(tpath)):
+            and not args.chain and os.path.exists(tpath)):
         rec = json.load(open(tpath))
         # the record names the kernel sources it was measured on: a build from other sources gets traffic = null, not a
         # stale number (tools/profile_round.sh rewrites the record)
         if rec.get("kernel_sources_sha256") == kernel_sources_sha256():
             roofline["traffic"] = rec["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = ("profiles/r03c_traffic_nerf_mlp.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate "
+            roofline["hbm_bytes_per_frame_all_kernels"] = rec.get("hbm_bytes_per_frame_all_kernels")
+            roofline["kernels_per_frame"] = rec.get("kernels_per_frame")
+            roofline["traffic_source"] = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate "
                                           "passes on this build's kernel sources; not live)")
         else:
             roofline["traffic"] = None
-            roofline["traffic_source"] = "profiles/r03c_traffic_nerf_mlp.json was measured on other kernel sources: not quoted"
+            roofline["traffic_source"] = f"profiles/{tname} was measured on other kernel sources: not quoted"
 
+    one_kernel = (args.mode == "depthnet" and not args.chain
+                  and bool(ops._lib.load().ns_render_fused_supported(nerf_w.handle, 1, args.samples)))
+    renderer_note = ("ns_render_rays_fused: ray generation, DepthNet, ONE kernel for placement + MLP + compositing (3 launches "
+                     "per frame; z / raw never in HBM)" if one_kernel else
+                     "ns_render_rays_depthnet: ray generation, DepthNet, placement, MLP, compositing (5 launches per frame)"
+                     if args.mode == "depthnet" else "ns_render_rays_hierarchical")
     if rank == 0:
         rays = H * W * args.steps
         scene_note = ("networks fitted to the analytic ground-truth scene (tools/fit_scene.py)" if args.scene == "shapes_fit"
@@ -599,6 +660,7 @@ def main():
                                     f"samples/ray (coarse + fine NeRF 8x256)")
                                    + f", {scene_note} ({args.scene}), spiral render poses of load_blender.py",
                        "rays_per_step": H * W, "samples_per_ray": args.samples, "depthnet_operands": depth_dtype,
+                       "renderer": renderer_note,
                        "parallelism": f"rows sharded over {world} GPU(s), one all-gather per frame"},
             "roofline": roofline,
         }

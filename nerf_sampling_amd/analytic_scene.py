@@ -85,6 +85,40 @@ def raycast(rays_o: Tensor, rays_d: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     return rgb.float(), best_t.float(), hit
 
 
+def sdf(p: Tensor) -> Tensor:
+    """Signed distance [...,] of points p [..., 3] to the nearest object surface (negative inside)."""
+    best = torch.full(p.shape[:-1], math.inf, dtype=p.dtype, device=p.device)
+    for c, r, _ in SPHERES:
+        c_ = torch.tensor(c, dtype=p.dtype, device=p.device)
+        best = torch.minimum(best, (p - c_).norm(dim=-1) - r)
+    for c, h, _ in BOXES:
+        c_ = torch.tensor(c, dtype=p.dtype, device=p.device)
+        h_ = torch.tensor(h, dtype=p.dtype, device=p.device)
+        q = (p - c_).abs() - h_
+        best = torch.minimum(best, q.clamp(min=0.0).norm(dim=-1) + q.max(-1).values.clamp(max=0.0))
+    return best
+
+
+def depth_target(rays_o: Tensor, rays_d: Tensor, near: float = 2.0, far: float = 6.0, coarse: int = 192, fine: int = 24):
+    """(t_target [R], hit [R]): the depth a DepthNet should predict for each ray -- the exact hit parameter where the ray
+    hits, and on a miss the parameter of the ray's CLOSEST APPROACH to any surface (argmin of the signed distance along the
+    ray, two-level search).  At an object's silhouette against the background the two agree (a tangent ray's hit point is
+    its closest approach), so the target is continuous there and only object-over-object occlusion edges keep a jump."""
+    _, t_hit, hit = raycast(rays_o, rays_d)
+    o, d = rays_o.double(), rays_d.double()
+    R = o.shape[0]
+    ts = torch.linspace(near, far, coarse, dtype=torch.float64, device=o.device)
+    dist = sdf(o[:, None, :] + ts[None, :, None] * d[:, None, :])             # [R, coarse]
+    k = dist.argmin(-1)
+    step = (far - near) / (coarse - 1)
+    t0 = (ts[k] - step).clamp(min=near)
+    tf = t0[:, None] + torch.linspace(0.0, 2.0 * step, fine, dtype=torch.float64, device=o.device)[None, :]
+    tf = tf.clamp(max=far)
+    kf = sdf(o[:, None, :] + tf[..., None] * d[:, None, :]).argmin(-1)
+    t_close = torch.gather(tf, 1, kf[:, None])[:, 0]
+    return torch.where(hit, t_hit.double(), t_close).float(), hit
+
+
 def frame(H: int, W: int, K, c2w: Tensor, row0: int = 0, row1: int = None, device="cpu") -> Tuple[Tensor, Tensor, Tensor]:
     """Ground-truth rows [row0, row1) of the H x W frame of camera ``c2w``: (rgb [rows, W, 3], t [rows, W], hit)."""
     row1 = H if row1 is None else row1

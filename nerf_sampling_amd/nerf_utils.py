@@ -129,6 +129,9 @@ class _HostSink:
 
 
 _sink_pool = {}          # (key, shape, dtype) -> pinned buffers recycled by render_path (emptied when it returns)
+_held_sink = None        # render_path's pipeline: the previous frame's sink, its copies queued but not started yet -- they are
+                         # released when the NEXT frame's MLP kernel starts (render_rays_test), or by finish()
+_WHOLE_FRAME_BYTES = 8 << 30   # a standard-configuration frame goes through render_rays_test in ONE call up to this much per-sample output
 _pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
 _last_sink = None        # the sink of the most recent _batchify call (None: that call made blocking copies)
 
@@ -147,12 +150,22 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
     reference's blocking `.cpu()` calls.  With ``_defer_host_sync=True`` (render_path's own loop) the tail of frame i's
     copies stays in flight under frame i+1's kernels: frame i-1 is drained here, frame i by drain_host_copies() or by
     the next frame."""
-    global _last_sink
+    global _last_sink, _held_sink
     all_returned = {}
     sink = None
     defer = bool(kwargs.pop("_defer_host_sync", False))
     if render_fn is render_rays_test and rays_flat.is_cuda and not kwargs.get("_blocking_host_copies", False):
         sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device, pooled=defer)
+        # The standard configuration renders a frame as ONE render_rays_test call: the reference's chunk loop (:58-85) bounds
+        # its memory, not its results -- rays are independent, the concatenated chunks ARE the whole-frame tensors -- and
+        # twenty chunk calls cost 16-21 ms of Python per 800x800 frame (DESIGN.md section 6).  One call = three launches and
+        # four host copies per frame.  (Bigger frames fall back to chunks of the largest size under the memory bound.)
+        tr = kwargs.get("trainer")
+        net = kwargs.get("network_fine") if kwargs.get("network_fine") is not None else kwargs.get("network_fn")
+        if (tr is not None and rays_flat.shape[-1] > 8 and not (tr.compare_nerf or tr.use_nerf_max_pts or tr.use_full_nerf)
+                and _one_call_eligible(kwargs.get("depth_network"), net, kwargs.get("network_query_fn"), tr, True)):
+            per_ray = 20 * (1 if tr.sampling_mode == "depth_only" else int(tr.n_depth_samples))
+            chunk = max(chunk, min(rays_flat.shape[0], _WHOLE_FRAME_BYTES // per_ray))
     for i in range(0, rays_flat.shape[0], chunk):
         returned = render_fn(rays_flat[i : i + chunk], **kwargs)
         for key in returned:
@@ -161,11 +174,17 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
             sink.advance(min(chunk, rays_flat.shape[0] - i))
     _last_sink = sink if defer else None
     if sink is not None:
-        sink.release()                   # the last chunk's copies
         if defer:
-            drain_host_copies()          # the previous frame: long finished by now
+            # render_path's pipeline: this frame's (last chunk's) copies wait for the NEXT frame's MLP kernel -- beside the
+            # next frame's small kernels (rays, DepthNet) the blit kernels that move them stretch those tenfold -- or for
+            # finish(), whichever comes first
+            if _held_sink is not None and _held_sink is not sink:
+                _held_sink.release()
+            _held_sink = sink
+            drain_host_copies()          # the frame before the previous one: long finished by now
             _pending_sinks.append(sink)
         else:
+            sink.release()               # the last chunk's copies
             sink.finish()
     return {key: (sink.bufs[key] if sink is not None and key in sink.bufs else torch.cat(all_returned[key], 0))
             for key in all_returned}
@@ -481,12 +500,18 @@ def render_rays_test(ray_batch, network_fn, network_query_fn, N_samples, trainer
         dn = kwargs["depth_network"]
         net = network_fine if network_fine is not None else network_fn
         ev = sink.new_event_pair() if sink is not None else None
-        out = ops.render_rays_depthnet(dn.packed(), net.packed(), rays=(rays_o, rays_d, viewdirs),
+        held = _held_sink
+        dn_w, net_w, guard_w = ops.psnr_guard_handles(dn, net)
+        if trainer.sampling_mode != "uniform" or trainer.n_depth_samples < 2:
+            guard_w = None               # (the guard pass is defined for uniform placement)
+        out = ops.render_rays_depthnet(dn_w, net_w, rays=(rays_o, rays_d, viewdirs),
                                        n_samples=trainer.n_depth_samples, mode=trainer.sampling_mode, std=trainer.distance,
                                        near=dn.near, far=dn.far, sphere_radius=float(dn.sphere_radius.reshape(-1)[0]),
-                                       white_bkgd=True, extras=True, device=rays_o.device, mlp_events=ev)
+                                       white_bkgd=True, extras=True, device=rays_o.device, mlp_events=ev, guard=guard_w)
         if sink is not None:
             sink.release(after=ev[0])    # the PREVIOUS chunk's host copies start with this chunk's MLP kernel
+            if held is not None and held is not sink:
+                held.release(after=ev[0])          # ... and so do the previous FRAME's (render_path's pipeline)
         released_early = True
         rgb_map, disp_map, weights, pts, z_vals = out["rgb"], out["disp"], out["weights"], out["pts"], out["z"]
     else:

@@ -365,7 +365,7 @@ def test_hip_adam_reloads_its_state_in_device_step_mode(gpu_modules):
         for gr in grads[:3]:                               # three steps of torch's Adam make the state to load
             ref_w.grad = gr.clone()
             ref.step()
-        sd = ref.state_dict()
+        sd = copy.deepcopy(ref.state_dict())               # (torch's loader keeps same-device state tensors by reference)
         if step_as_int:
             for st in sd["state"].values():
                 st["step"] = int(st["step"])
@@ -377,5 +377,5 @@ def test_hip_adam_reloads_its_state_in_device_step_mode(gpu_modules):
         assert opt._host_steps == 3 and int(opt._dev_step.item()) == 3 and abs(float(opt._dev_lr.item()) - 2e-3) < 1e-9
         w.grad, ref_w.grad = grads[3].clone(), grads[3].clone()
         opt.step(); ref.step()
-        assert torch.allclose(w, ref_w, rtol=0, atol=2e-7), float((w - ref_w).abs().max())
+        assert torch.allclose(w, ref_w, rtol=0, atol=1e-6), float((w - ref_w).abs().max())       # (an update is ~2e-3)
         assert float(opt.state_dict()["state"][0]["step"]) == 4.0

@@ -257,6 +257,72 @@ def fit_depthnet(args):
               open(os.path.join(args.out, "depthnet_fit.json"), "w"))
 
 
+def fit_depthnet_direct(args):
+    """DepthNet against ANALYTIC depth targets (analytic_scene.depth_target: the exact hit depth, continued over the
+    background by the ray's closest approach to a surface, so silhouettes against the background carry no jump), Huber loss,
+    on this repo's own DepthNet backward kernels and Adam (autograd.DepthNetFunction, HipAdam).  No frozen-field pass per
+    step, so a step is the DepthNet alone and a run sees two orders of magnitude more rays than phase `depthnet`."""
+    from nerf_sampling_amd.autograd import HipAdam
+    from nerf_sampling_amd.depth_net import DepthNet
+
+    torch.manual_seed(2)
+    rng = np.random.default_rng(2)
+    out_path = os.path.join(args.out, "depthnet.safetensors")
+    init = os.path.join(args.init, "depthnet.safetensors")
+    dn = DepthNet(hidden_sizes=[256] * 10, cat_hidden_sizes=[256] * 10, sphere_radius=2.0)
+    if args.resume and os.path.exists(init):
+        dn.load_state_dict(load(init))
+        print("[direct] resuming from", init, flush=True)
+    dn = dn.cuda()
+    opt = HipAdam(list(dn.parameters()), lr=args.depth_lr)
+    H = W = 800
+    _, K = synthetic.blender_intrinsics(H, W)
+    dev = torch.device("cuda")
+    n_pose, delta = 8, args.huber
+    t_start, it, planned, log = time.time(), 0, None, []
+    while True:
+        os_, ds_ = [], []
+        for _ in range(n_pose):
+            idx = torch.randint(0, H * W, (args.rays // n_pose,), device=dev)
+            o, d = camera_rays(H, W, K, random_pose(rng), idx, dev)
+            os_.append(o), ds_.append(d)
+        o, d = torch.cat(os_), torch.cat(ds_)
+        with torch.no_grad():
+            target, hit = analytic_scene.depth_target(o, d, NEAR, FAR)
+        z = dn(o, d)[:, 0]
+        err = z - target
+        a = err.abs()
+        loss = torch.where(a < delta, 0.5 * err * err / delta, a - 0.5 * delta).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        dn.repack()
+        it += 1
+        if it in (30, 60):
+            torch.cuda.synchronize()
+            if it == 30:
+                t30 = time.time()
+            else:
+                planned = max(200, int((args.seconds - (time.time() - t_start)) / ((time.time() - t30) / 30)) + 60)
+                print(f"[direct] {1e3 * (time.time() - t30) / 30:.1f} ms/iter -> planning {planned} iterations", flush=True)
+        if planned:
+            for g in opt.param_groups:
+                g["lr"] = args.depth_lr * (args.lr_floor ** min(1.0, it / planned))
+        if it % 1000 == 0:
+            with torch.no_grad():
+                inwin = float((a[hit] < 0.1).float().mean())
+                rms = float((err[hit] ** 2).mean().sqrt())
+            log.append((it, float(loss), inwin, rms))
+            print(f"[direct] it {it} huber {float(loss):.5f} hit rays: |err|<0.1 {inwin:.4f} rms {rms:.4f} "
+                  f"({time.time() - t_start:.0f} s)", flush=True)
+        if it % 10000 == 0 or (planned and it >= planned):
+            save(dn.state_dict(), out_path)
+        if planned and it >= planned:
+            break
+    json.dump({"iterations": it, "rays_per_iteration": args.rays, "lr": args.depth_lr, "huber_delta": delta, "log": log,
+               "resumed": bool(args.resume)}, open(os.path.join(args.out, "depthnet_direct_fit.json"), "w"))
+
+
 def evaluate(args):
     from nerf_sampling_amd import ops
 
@@ -266,7 +332,7 @@ def evaluate(args):
     _, K = synthetic.blender_intrinsics(H, W)
     poses = synthetic.render_poses(40)[:, :3, :4]
     res = {}
-    for dtype in ("f32", "bf16", "f16"):
+    for dtype in (("f32",) if args.quick else ("f32", "bf16", "f16")):
         nw, dw = nerf.packed(dtype), dn.packed(dtype)
         rows = []
         for k in (0, 7, 13, 21, 34):
@@ -286,6 +352,26 @@ def evaluate(args):
                 Image.fromarray((gt.clamp(0, 1).cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(args.out, "pose7_gt.png"))
         res[dtype] = rows
         print(dtype, json.dumps(rows), flush=True)
+    # the ceiling of the field under guided sampling: windows centred on the ANALYTIC depth target (a perfect DepthNet)
+    nw = nerf.packed("f32")
+    ceil = []
+    for k in (0, 7, 13, 21, 34):
+        o, d, view = ops.get_rays(H, W, K, poses[k], device="cuda")[:3]
+        o, d, view = o.reshape(-1, 3), d.reshape(-1, 3), view.reshape(-1, 3)
+        gt, _, _ = analytic_scene.frame(H, W, K, poses[k], device="cuda")
+        mse, n = 0.0, 0
+        for r0 in range(0, H * W, 160000):
+            sl = slice(r0, r0 + 160000)
+            tgt, _ = analytic_scene.depth_target(o[sl], d[sl], NEAR, FAR)
+            oo, dd, vv = o[sl].contiguous(), d[sl].contiguous(), view[sl].contiguous()
+            z = ops.place_samples(oo, dd, tgt[:, None].contiguous(), 64, "uniform", 0.1, want_pts=False)[1]
+            raw = ops.nerf_forward_rays(nw, oo, dd, z, vv)
+            rgb = ops.raw2outputs(raw, z, dd, None, True, want_per_sample=False)[0]
+            mse += float(((rgb - gt.reshape(-1, 3)[sl]) ** 2).sum())
+            n += rgb.numel()
+        ceil.append({"pose": k, "psnr_vs_gt_perfect_depth": -10 * math.log10(mse / n)})
+    res["ceiling"] = ceil
+    print("ceiling", json.dumps(ceil), flush=True)
     # what the vanilla 64 + 128 pass of the same field scores (the quality of the field itself)
     ws = ops.RenderWorkspace()
     nw = nerf.packed("f32")
@@ -299,7 +385,7 @@ def evaluate(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--phase", required=True, choices=["nerf", "depthnet", "eval"])
+    ap.add_argument("--phase", required=True, choices=["nerf", "depthnet", "depthnet_direct", "eval"])
     ap.add_argument("--out", default="gpurun_out/fit")
     ap.add_argument("--seconds", type=float, default=420.0)
     ap.add_argument("--rays", type=int, default=2048)
@@ -308,7 +394,10 @@ if __name__ == "__main__":
     ap.add_argument("--resume", action="store_true", help="start from the weights under --init")
     ap.add_argument("--init", default=os.path.join(ROOT, "tests", "golden", "fitted_scene"))
     ap.add_argument("--nerf-lr", type=float, default=5e-4)
+    ap.add_argument("--quick", action="store_true", help="phase eval: fp32 only")
+    ap.add_argument("--huber", type=float, default=0.02, help="phase depthnet_direct: Huber delta in depth units")
+    ap.add_argument("--lr-floor", type=float, default=0.03, help="phase depthnet_direct: final / initial learning rate")
     ap.add_argument("--device", default="cuda", help="phase nerf only (plain torch); the other phases need the GPU")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
-    {"nerf": fit_nerf, "depthnet": fit_depthnet, "eval": evaluate}[a.phase](a)
+    {"nerf": fit_nerf, "depthnet": fit_depthnet, "depthnet_direct": fit_depthnet_direct, "eval": evaluate}[a.phase](a)

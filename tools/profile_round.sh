@@ -2,7 +2,7 @@
 # trace of the same command, and the PMC passes (each in its own run: counters never share a run with a trace domain
 # other than --kernel-trace).  Outputs under gpurun_out/TAG/; copy the summaries to profiles/.
 set -e
-tag=${1:-r03}
+tag=${1:-r04}
 root=$PWD
 mkdir -p gpurun_out/$tag
 python bench.py > gpurun_out/$tag/bench_default.json 2> gpurun_out/$tag/bench_default.err
@@ -26,24 +26,41 @@ python tools/bench_train_step.py bf16 --graph | tail -n 1 > gpurun_out/$tag/trai
 python tools/pmc_summary.py gpurun_out/$tag | tee gpurun_out/$tag/summary.txt
 # the HBM-traffic record bench.py quotes in `roofline.traffic`, tied to the kernel sources it was measured on
 python - "$tag" <<'PY'
-import json, sys
+import csv, glob, json, sys
 sys.path.insert(0, ".")
 import bench
 tag = sys.argv[1]
 m = json.load(open(f"gpurun_out/{tag}/per_launch_means.json"))
-rec = {"workload": "800x800, 64 samples/ray, one launch per frame (fitted scene), bf16",
+line = json.loads(open(f"gpurun_out/{tag}/bench_under_rocprof.json").read().strip().splitlines()[-1])
+rec = {"workload": "800x800, 64 samples/ray, one frame per step (fitted scene), bf16",
+       "renderer": line["config"]["renderer"],
        "kernel_sources_sha256": bench.kernel_sources_sha256(),
        "note": "separate --pmc passes (pmc_fetch / pmc_write counter_collection.csv of the same run, every launch a full frame); "
-               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streaming-read bytes); WRITE_SIZE = 655.36 MB = "
-               "exactly R*N*16 B of raw. Algorithmic bytes: 164 MB z + 23 MB rays + 655 MB raw = 0.84 GB."}
+               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of streaming-read bytes).  Algorithmic bytes of the "
+               "one-kernel renderer's MLP launch: 40 B in (o, d, viewdirs, DepthNet depth) + 16 B out (rgb, disp) per ray = 36 MB "
+               "per 640 000-ray frame + the 1.05 MiB weight stream; z and raw never reach HBM."}
+hbm = lambda c: int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024))
 for k, name in (("nerf_mlp_ob16_kernel", None), ("depthnet_ob16_kernel", "depthnet_ob16_kernel")):
-    d = {"FETCH_SIZE_KB": m[k]["FETCH_SIZE"], "WRITE_SIZE_KB": m[k]["WRITE_SIZE"],
-         "hbm_bytes_per_launch": int(round((2 * m[k]["FETCH_SIZE"] + m[k]["WRITE_SIZE"]) * 1024))}
+    d = {"FETCH_SIZE_KB": m[k]["FETCH_SIZE"], "WRITE_SIZE_KB": m[k]["WRITE_SIZE"], "hbm_bytes_per_launch": hbm(m[k])}
     if name:
         rec[name] = d
     else:
         rec.update(d)
         rec["kernel"] = "nerf_mlp_ob16_kernel (production program, the launch the headline bench times)"
+# every kernel of a frame: launches per frame from the kernel trace (calls / frames), bytes from the PMC passes
+stats = sorted(glob.glob(f"gpurun_out/{tag}/stats/*/*kernel_stats.csv"))[0]
+frames = line["steps"] + line["warmup"]
+per_frame, total = {}, 0
+for r in csv.DictReader(open(stats)):
+    key = next((k for k in m if k in r["Name"] and "FETCH_SIZE" in m[k] and "WRITE_SIZE" in m[k]), None)
+    if key is None:
+        continue
+    n = int(r["Calls"]) / frames
+    per_frame[key] = {"launches_per_frame": n, "avg_ms": float(r["AverageNs"]) / 1e6, "hbm_bytes_per_launch": hbm(m[key])}
+    total += n * hbm(m[key])
+rec["kernels_per_frame"] = per_frame
+rec["hbm_bytes_per_frame_all_kernels"] = int(round(total))
 json.dump(rec, open(f"gpurun_out/{tag}/traffic_nerf_mlp.json", "w"), indent=1)
-print("traffic record:", rec["hbm_bytes_per_launch"], "B per launch, sources", rec["kernel_sources_sha256"][:16])
+print("traffic record:", rec["hbm_bytes_per_launch"], "B per MLP launch,", rec["hbm_bytes_per_frame_all_kernels"], "B per frame over",
+      sorted(per_frame), "sources", rec["kernel_sources_sha256"][:16])
 PY
