@@ -31,6 +31,11 @@ struct DebugFlags {
   int prod_tiles;        // 4 / 5: tiles per wave of the 16-bit production kernel; 0 = chosen per launch
 };
 DebugFlags& debug_flags();
+// Per-thread launch hint of the one-call renderers (ns_render.cpp): 4 = this call's per-sample outputs are about to be
+// copied to the host while the NEXT call's MLP kernel runs -- the four-tile production kernel leaves 64+ registers of every
+// SIMD free, so the blit kernels ROCm moves pinned device-to-host copies with can run beside it; the five-tile kernel
+// (2.5 % faster alone) fills the register file and the copies would wait for the whole persistent grid.  0 = no preference.
+int& prod_tiles_hint();
 
 int cu_count();
 hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);

@@ -63,6 +63,11 @@ DebugFlags& debug_flags() {
   return f;
 }
 
+int& prod_tiles_hint() {
+  static thread_local int hint = 0;
+  return hint;
+}
+
 }  // namespace ns
 
 extern "C" {

@@ -635,6 +635,7 @@ int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
     auto rounds = [&](int64_t per_group) { const int64_t g = (a.S + per_group - 1) / per_group; return (g + cus - 1) / cus; };
     const double t4 = static_cast<double>(rounds(kWaves * 4 * 16)) * 4.0, t5 = static_cast<double>(rounds(kWaves * 5 * 16)) * 5.0 * 0.975;
     int tiles = NS_OB16_PROD_T ? NS_OB16_PROD_T : (t5 < t4 ? 5 : 4);
+    if (ns::prod_tiles_hint()) tiles = ns::prod_tiles_hint();               // the renderer's hint (host copies in flight)
     if (ns::debug_flags().prod_tiles) tiles = ns::debug_flags().prod_tiles;   // diagnostic override (ns_debug_set)
     if (tiles == 5) return nsob16::launch_prod_t5(M::kDtype, EMB, a, stream);
     return launch<M, 8, EMB, true, 4>(a, stream);

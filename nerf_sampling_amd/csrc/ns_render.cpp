@@ -100,7 +100,9 @@ int ns_render_rays_depthnet(const ns_render_args* a, void* stream) {
   rc = ns_place_samples(a->mode, o, d, mean, a->noise_dev, R, N, a->std_, a->pts_dev, z, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
+  ns::prod_tiles_hint() = (a->z_dev || a->weights_dev || a->pts_dev) ? 4 : 0;   // per-sample outputs: host copies will run beside the next MLP kernel
   rc = ns_nerf_forward(a->nerf, nullptr, o, d, z, view, R, N, raw, stream);
+  ns::prod_tiles_hint() = 0;
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
   if (a->nerf_guard) {
@@ -176,7 +178,9 @@ int ns_render_rays_fused(const ns_render_args* a, void* stream) {
     c.sigma_last_dev = raw_last;
   }
   if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
+  ns::prod_tiles_hint() = (a->z_dev || a->weights_dev || a->pts_dev) ? 4 : 0;   // (see ns_common.h)
   rc = ns_nerf_forward_ob16(a->nerf, nullptr, o, d, nullptr, view, nullptr, R * a->N, a->N, nullptr, ns::as_stream(stream), &c);
+  ns::prod_tiles_hint() = 0;
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
   return NS_OK;

@@ -131,7 +131,12 @@ class _HostSink:
 _sink_pool = {}          # (key, shape, dtype) -> pinned buffers recycled by render_path (emptied when it returns)
 _held_sink = None        # render_path's pipeline: the previous frame's sink, its copies queued but not started yet -- they are
                          # released when the NEXT frame's MLP kernel starts (render_rays_test), or by finish()
-_WHOLE_FRAME_BYTES = 8 << 30   # a standard-configuration frame goes through render_rays_test in ONE call up to this much per-sample output
+# A standard-configuration frame may go through render_rays_test in ONE call when its per-sample outputs fit this many bytes
+# (NS_WHOLE_FRAME_BYTES; 0 = off, the default: the reference's chunk loop).  Measured on MI355X, 800x800x64, render_path steady
+# state (profiles/r04_api_path_whole_frame_vs_chunks.log): one call per frame 35.5 ms, twenty chunks 30.5 ms -- the path is bound
+# by the device-to-host copies (0.82 GB per frame at ~27 GB/s beside the MLP kernel), and chunks let them start a chunk
+# after the frame does instead of a frame later; the 16-21 ms of Python the chunk loop costs stay hidden under the GPU's 27.
+_WHOLE_FRAME_BYTES = int(os.environ.get("NS_WHOLE_FRAME_BYTES", 0))
 _pending_sinks = []      # frames whose host copies may still be in flight (only with _defer_host_sync, see _batchify)
 _last_sink = None        # the sink of the most recent _batchify call (None: that call made blocking copies)
 
@@ -156,10 +161,10 @@ def _batchify(render_fn, rays_flat, chunk, **kwargs):
     defer = bool(kwargs.pop("_defer_host_sync", False))
     if render_fn is render_rays_test and rays_flat.is_cuda and not kwargs.get("_blocking_host_copies", False):
         sink = kwargs["_host_sink"] = _HostSink(rays_flat.shape[0], rays_flat.device, pooled=defer)
-        # The standard configuration renders a frame as ONE render_rays_test call: the reference's chunk loop (:58-85) bounds
-        # its memory, not its results -- rays are independent, the concatenated chunks ARE the whole-frame tensors -- and
-        # twenty chunk calls cost 16-21 ms of Python per 800x800 frame.  One call = three launches and
-        # four host copies per frame.  (Bigger frames fall back to chunks of the largest size under the memory bound.)
+        # Optionally (_WHOLE_FRAME_BYTES > 0) the standard configuration renders a frame as ONE render_rays_test call: the
+        # reference's chunk loop (:58-85) bounds its memory, not its results -- rays are independent, the concatenated chunks
+        # ARE the whole-frame tensors.  One call = three launches and four host copies per frame; bigger frames fall back to
+        # chunks of the largest size under the bound.  Off by default: see _WHOLE_FRAME_BYTES.
         tr = kwargs.get("trainer")
         net = kwargs.get("network_fine") if kwargs.get("network_fine") is not None else kwargs.get("network_fn")
         if (tr is not None and rays_flat.shape[-1] > 8 and not (tr.compare_nerf or tr.use_nerf_max_pts or tr.use_full_nerf)

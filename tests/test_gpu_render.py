@@ -722,9 +722,9 @@ def test_rays_missing_the_sphere_render_nan(gpu_modules, dtype):
 @pytest.mark.parametrize("ns,mode", [(16, "uniform"), (1, "depth_only")])
 def test_standard_configuration_takes_the_one_call_path_bit_exactly(gpu_modules, dtype, ns, mode):
     """render_rays_test with the query function create_nerf builds (tagged standard) runs its DepthNet branch as ONE C
-    call -- and render_test hands it the WHOLE frame in one call instead of the reference's chunk loop (nerf_utils.py:58-85;
-    rays are independent: the concatenated chunks are the whole-frame tensors) -- while an untagged query function runs the
-    operator chain chunk by chunk.  Same keys, shapes, placement and bits; a frame over the memory bound is chunked again."""
+    call per chunk; an untagged query function runs the operator chain.  Same keys, shapes, placement and bits.  With
+    nerf_utils._WHOLE_FRAME_BYTES raised, render_test hands the standard configuration whole frames (or the largest chunks
+    under the bound) instead of the reference's chunk size (nerf_utils.py:58-85): rays are independent, same bits again."""
     from nerf_sampling_amd import nerf_utils, ops
 
     ops.set_compute_dtype(dtype)
@@ -744,25 +744,26 @@ def test_standard_configuration_takes_the_one_call_path_bit_exactly(gpu_modules,
         fused = nerf_utils.render_test(H, W, K, chunk=150, c2w=c2w, **kw2)
     finally:
         ops.render_rays_depthnet = orig
-    assert len(calls) == 1                                        # 437 rays: one call, not three chunks of 150
+    assert len(calls) == 3                                        # 437 rays in chunks of 150
     assert torch.equal(chain[0], fused[0]) and torch.equal(chain[1].cpu(), fused[1].cpu())
     assert set(chain[2]) == set(fused[2])
     for k in chain[2]:
         assert chain[2][k].shape == fused[2][k].shape and chain[2][k].is_cuda == fused[2][k].is_cuda, k
         assert torch.equal(chain[2][k].cpu(), fused[2][k].cpu()), k
-    # the memory bound of the whole-frame call: with room for 200 rays' per-sample outputs the frame is chunked again
-    calls.clear()
+    # whole-frame calls: room for every ray's per-sample outputs -> one call; room for 200 rays -> 200 + 200 + 37
     keep = nerf_utils._WHOLE_FRAME_BYTES
-    nerf_utils._WHOLE_FRAME_BYTES = 200 * 20 * ns
-    ops.render_rays_depthnet = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    try:
-        again = nerf_utils.render_test(H, W, K, chunk=150, c2w=c2w, **kw2)
-    finally:
-        ops.render_rays_depthnet = orig
-        nerf_utils._WHOLE_FRAME_BYTES = keep
-    assert len(calls) == 3 and torch.equal(again[0], fused[0])   # chunks of 200 rays: 200 + 200 + 37
-    for k in chain[2]:
-        assert torch.equal(chain[2][k].cpu(), again[2][k].cpu()), k
+    for bound, n_calls in ((1 << 30, 1), (200 * 20 * ns, 3)):
+        calls.clear()
+        nerf_utils._WHOLE_FRAME_BYTES = bound
+        ops.render_rays_depthnet = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            again = nerf_utils.render_test(H, W, K, chunk=150, c2w=c2w, **kw2)
+        finally:
+            ops.render_rays_depthnet = orig
+            nerf_utils._WHOLE_FRAME_BYTES = keep
+        assert len(calls) == n_calls and torch.equal(again[0], fused[0])
+        for k in chain[2]:
+            assert torch.equal(chain[2][k].cpu(), again[2][k].cpu()), k
 
 
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
