@@ -354,6 +354,17 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     rgb, disp = ops.raw2outputs(ops.nerf_forward_rays(nf, o, d, z, view), z, d, None, True)[:2]
     out = ops.render_rays_depthnet(dn, nf, rays=(o, d, view), n_samples=64, mode="uniform", std=0.1, shard=shard, one_kernel=True)
     assert torch.equal(shard[:, :3], rgb) and torch.equal(shard[:, 3], disp) and out["rgb"].data_ptr() == shard.data_ptr()
+    # rays that miss the DepthNet's sphere: NaN depth, NaN samples, NaN pixel -- in both renderers, bit for bit, and only there
+    o2, d2 = o.clone(), d.clone()
+    miss = torch.arange(0, o.shape[0], 7, device="cuda")
+    d2[miss] = torch.tensor([0.0, 0.0, 1.0], device="cuda")          # pointing away from the scene
+    for n in (64, 16):
+        a = ops.render_rays_depthnet(dn, nf, rays=(o2, d2, view), n_samples=n, mode="uniform", std=0.1, extras=True, one_kernel=True)
+        b = ops.render_rays_depthnet(dn, nf, rays=(o2, d2, view), n_samples=n, mode="uniform", std=0.1, extras=True, one_kernel=False)
+        for k in ("rgb", "disp", "z", "weights", "pts"):
+            assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (n, k)
+        nan_rays = torch.isnan(a["rgb"]).any(-1)
+        assert nan_rays[miss].all() and int(nan_rays.sum()) == miss.numel()
 
 
 
