@@ -289,6 +289,28 @@ int ns_render_rays_hierarchical(const ns_hier_args* args, void* stream);
 int ns_gemm_strided(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0,
                     int64_t sb1, const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K,
                     int accumulate, void* stream);
+/* The same GEMM with fused epilogues (a training step is launch-bound: every elementwise kernel beside a GEMM costs as much
+ * as a small GEMM): act != 0 applies an activation to the result (0 none, 1 relu, 2 leaky 0.01, 3 sigmoid: a forward
+ * layer); dact != 0 multiplies the result by the derivative of activation `dact` evaluated from its OUTPUT
+ * dact_ref[i*ld_ref + j] (the grad-input GEMM of the layer above carries the backward through this layer's activation);
+ * a_rowsum [M], if non-NULL, receives sum_k A[i,k] (the bias gradient when A = dy^T, i.e. of the grad-weight GEMM).      */
+int ns_gemm_fused(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0,
+                  int64_t sb1, const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K,
+                  int accumulate, int act, int dact, const float* dact_ref_dev, int64_t ld_ref,
+                  float* a_rowsum_dev, void* stream);
+/* Up to four such GEMMs in ONE launch (the three skip branches of the DepthNet run the same layer side by side); all
+ * problems of a launch share their operand layout (sa1 == 1 or not, sb1 == 1 or not).  problems_host: HOST array.     */
+typedef struct ns_gemm_problem {
+  const float* A_dev; int64_t sa0, sa1;
+  const float* B_dev; int64_t sb0, sb1;
+  const float* bias_dev;
+  float* C_dev; int64_t ldc;
+  int M, N, K;
+  int accumulate, act, dact;
+  const float* dact_ref_dev; int64_t ld_ref;
+  float* a_rowsum_dev;
+} ns_gemm_problem;
+int ns_gemm_fused_batched(const ns_gemm_problem* problems_host, int count, void* stream);
 /* out[j] = sum_i X[i*ld + j]  (bias gradient) */
 int ns_colsum(const float* X_dev, int64_t ld, int M, int N, float* out_dev, void* stream);
 /* activations in place: act 0 none, 1 ReLU, 2 LeakyReLU(0.01), 3 sigmoid; backward scales dy by act'(.)

@@ -42,6 +42,21 @@ class RenderArgs(C.Structure):
     ]
 
 
+class GemmProblem(C.Structure):
+    """struct ns_gemm_problem"""
+
+    _fields_ = [
+        ("A_dev", _p), ("sa0", _i64), ("sa1", _i64),
+        ("B_dev", _p), ("sb0", _i64), ("sb1", _i64),
+        ("bias_dev", _p),
+        ("C_dev", _p), ("ldc", _i64),
+        ("M", _i), ("N", _i), ("K", _i),
+        ("accumulate", _i), ("act", _i), ("dact", _i),
+        ("dact_ref_dev", _p), ("ld_ref", _i64),
+        ("a_rowsum_dev", _p),
+    ]
+
+
 class HierArgs(C.Structure):
     """struct ns_hier_args"""
 
@@ -99,6 +114,8 @@ SIGNATURES = {
     "ns_hier_workspace_bytes": (_i64, [_i64, _i, _i]),
     "ns_render_rays_hierarchical": (_i, [C.POINTER(HierArgs), _p]),
     "ns_gemm_strided": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _i, _p]),
+    "ns_gemm_fused": (_i, [_p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _p, _i64, _p, _p]),
+    "ns_gemm_fused_batched": (_i, [C.POINTER(GemmProblem), _i, _p]),
     "ns_colsum": (_i, [_p, _i64, _i, _i, _p, _p]),
     "ns_act_forward": (_i, [_p, _i64, _i, _p]),
     "ns_act_backward": (_i, [_p, _p, _i64, _i, _p]),

@@ -29,13 +29,37 @@ NONE, RELU, LEAKY, SIGMOID = 0, 1, 2, 3
 
 
 def _gemm(A: Tensor, sa0: int, sa1: int, B: Tensor, sb0: int, sb1: int, bias: Optional[Tensor], M: int, N: int, K: int,
-          out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+          out: Optional[Tensor] = None, accumulate: bool = False, act: int = 0, dact: int = 0,
+          dact_ref: Optional[Tensor] = None, a_rowsum: Optional[Tensor] = None) -> Tensor:
+    """C = A B^T (+ bias) through ns_gemm_fused; ``out`` may be a strided [M, N] view (its row stride is the leading
+    dimension).  Epilogues: ``act`` on the result; ``dact``: result *= act'(.) evaluated from the activation OUTPUT
+    ``dact_ref`` [M, N] (may be strided); ``a_rowsum`` [M] <- sum_k A[i, k]."""
     lib = _lib.load()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    check(lib.ns_gemm_strided(_ptr(A), sa0, sa1, _ptr(B), sb0, sb1, _ptr(bias), _ptr(out), out.stride(0), M, N, K,
-                              int(accumulate), _stream(A.device)), "ns_gemm_strided")
+    check(lib.ns_gemm_fused(_ptr(A), sa0, sa1, _ptr(B), sb0, sb1, _ptr(bias), _ptr(out), out.stride(0), M, N, K,
+                            int(accumulate), int(act), int(dact), _ptr(dact_ref), 0 if dact_ref is None else dact_ref.stride(0),
+                            _ptr(a_rowsum), _stream(A.device)), "ns_gemm_fused")
     return out
+
+
+def _gemm_batched(problems) -> None:
+    """Up to four GEMMs of the same kind in ONE launch (ns_gemm_fused_batched).  Each problem: the keyword arguments of
+    ``_gemm`` with ``out`` given (A, sa0, sa1, B, sb0, sb1, bias, M, N, K, out, accumulate, act, dact, dact_ref, a_rowsum)."""
+    lib = _lib.load()
+    arr = (_lib.GemmProblem * len(problems))()
+    dev = problems[0]["A"].device
+    for q, pr in zip(arr, problems):
+        out, ref = pr["out"], pr.get("dact_ref")
+        q.A_dev, q.sa0, q.sa1 = pr["A"].data_ptr(), pr["sa0"], pr["sa1"]
+        q.B_dev, q.sb0, q.sb1 = pr["B"].data_ptr(), pr["sb0"], pr["sb1"]
+        q.bias_dev = None if pr.get("bias") is None else pr["bias"].data_ptr()
+        q.C_dev, q.ldc = out.data_ptr(), out.stride(0)
+        q.M, q.N, q.K = pr["M"], pr["N"], pr["K"]
+        q.accumulate, q.act, q.dact = int(pr.get("accumulate", False)), int(pr.get("act", 0)), int(pr.get("dact", 0))
+        q.dact_ref_dev, q.ld_ref = (None, 0) if ref is None else (ref.data_ptr(), ref.stride(0))
+        q.a_rowsum_dev = None if pr.get("a_rowsum") is None else pr["a_rowsum"].data_ptr()
+    check(lib.ns_gemm_fused_batched(arr, len(problems), _stream(dev)), "ns_gemm_fused_batched")
 
 
 def linear_forward(x: Tensor, W: Tensor, b: Optional[Tensor], act: int = NONE) -> Tensor:
@@ -142,41 +166,60 @@ class NerfInputGrad(torch.autograd.Function):
         net = ctx.net
         R, N = pts.shape[0], pts.shape[1]
         flat = pts.reshape(-1, 3).contiguous()
-        dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3).contiguous()
-        xe, ve = ops.posenc(flat, 10), ops.posenc(dirs, 4)
+        xe = ops.posenc(flat, 10)
         skips = net._check_supported()
-        if not net.use_viewdirs:
-            raise NotImplementedError("the input gradient is implemented for networks with view directions (the reference "
-                                      "trains its DepthNet against use_viewdirs=True fields, lego.yaml:11)")
         lins = list(net.pts_linears)
-        acts, ins = [], []
+        M = xe.shape[0]
+
+        def fwd(x, lin, act):              # act(x W^T + b), activation in the GEMM epilogue
+            return _gemm(x, x.stride(0), 1, lin.weight, lin.weight.shape[1], 1, lin.bias, M, lin.weight.shape[0], x.shape[1], act=act)
+
+        def bwd(dy, lin, n_cols=None, dref=None):   # dy W[:, :n_cols], times relu'(dref) when the layer below has a ReLU
+            Wt = lin.weight
+            return _gemm(dy, dy.stride(0), 1, Wt, 1, Wt.shape[1], None, M, n_cols or Wt.shape[1], dy.shape[1],
+                         dact=RELU if dref is not None else 0, dact_ref=dref)
+
+        acts = []
         h = xe
         for i, lin in enumerate(lins):                      # recompute (run_nerf_helpers.py:114-118)
-            ins.append(h)
-            h = linear_forward(h, lin.weight, lin.bias, RELU)
+            h = fwd(h, lin, RELU)
             acts.append(h)
             if i in skips:
                 h = torch.cat([xe, h], -1)
-        feat = linear_forward(h, net.feature_linear.weight, net.feature_linear.bias)
-        vin = torch.cat([feat, ve], -1)
-        hv = linear_forward(vin, net.views_linears[0].weight, net.views_linears[0].bias, RELU)
-        # backward
-        g = _dev(draw, "draw").reshape(-1, 4)
-        d_hv = linear_backward_input(g[:, :3].contiguous(), net.rgb_linear.weight)
-        act_backward_(d_hv, hv, RELU)
-        W = net.W
-        d_feat = linear_backward_input(d_hv, net.views_linears[0].weight, n_cols=W)
-        d_h = linear_backward_input(d_feat, net.feature_linear.weight)
-        d_h = d_h + linear_backward_input(g[:, 3:4].contiguous(), net.alpha_linear.weight)
+        last = len(lins) - 1
+        # d h_last: through the head, then times relu'(trunk output) -- the trunk's last activation.  When that output was
+        # concatenated with the embedding (a skip after the last layer cannot occur: _check_supported), plain [M, W].
+        if net.use_viewdirs:              # alpha / feature / views / rgb head (run_nerf_helpers.py:119-131)
+            dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3).contiguous()
+            ve = ops.posenc(dirs, 4)
+            feat = fwd(h, net.feature_linear, NONE)
+            vin = torch.cat([feat, ve], -1)
+            hv = fwd(vin, net.views_linears[0], RELU)
+            g = _dev(draw, "draw").reshape(-1, 4)
+            g_rgb, g_sigma = g[:, :3], g[:, 3:4]                         # strided views, no copies
+            d_hv = bwd(g_rgb, net.rgb_linear, dref=hv)
+            d_feat = bwd(d_hv, net.views_linears[0], n_cols=net.W)
+            d_h = bwd(d_feat, net.feature_linear)
+            # + the sigma head, accumulated in place, then the trunk's last ReLU on the sum
+            Wa = net.alpha_linear.weight
+            _gemm(g_sigma, g_sigma.stride(0), 1, Wa, 1, Wa.shape[1], None, M, Wa.shape[1], 1, out=d_h, accumulate=True,
+                  dact=RELU, dact_ref=acts[last])
+        else:                             # output_linear head (:132-133): raw = h W_out^T + b, no view directions
+            g = _dev(draw, "draw").reshape(-1, net.output_channels)
+            d_h = bwd(g, net.output_linear, dref=acts[last])
         d_xe = torch.zeros_like(xe)
-        for i in range(len(lins) - 1, -1, -1):
-            if i in skips:                                  # output of layer i was concatenated as cat[xe, h]
-                d_xe = d_xe + d_h[:, :63]
-                d_h = d_h[:, 63:].contiguous()
-            act_backward_(d_h, acts[i], RELU)
-            d_in = linear_backward_input(d_h, lins[i].weight)
-            d_h = d_in
-        d_xe = d_xe + d_h                                   # layer 0 input is xe
+        for i in range(last, -1, -1):     # d_h is the gradient w.r.t. the PRE-activation of layer i here
+            below = i - 1
+            if below >= 0 and below in skips:               # layer i saw cat[xe, h_{i-1}]
+                d_in = bwd(d_h, lins[i])                     # [M, 63 + W]: the xe part has no activation
+                d_xe = d_xe + d_in[:, :63]
+                d_h = d_in[:, 63:].contiguous()
+                act_backward_(d_h, acts[below], RELU)
+            elif below >= 0:
+                d_h = bwd(d_h, lins[i], dref=acts[below])
+            else:
+                d_h = bwd(d_h, lins[i])                      # layer 0's input is xe
+        d_xe = d_xe + d_h
         dpts = posenc_backward(flat, d_xe.contiguous(), 10)
         return dpts.reshape(R, N, 3), None, None
 
@@ -184,7 +227,13 @@ class NerfInputGrad(torch.autograd.Function):
 # ---- DepthNet, gradient w.r.t. its weights -----------------------------------------------------------------
 class DepthNetFunction(torch.autograd.Function):
     """forward/backward of depth_net.py:117-169 layer by layer (affine skip branches, LeakyReLU trunk, sigmoid
-    head).  params = [w, b] * (4 n + 1) in the order origin, direction, intersection, trunk, head."""
+    head).  params = [w, b] * (4 n + 1) in the order origin, direction, intersection, trunk, head.
+
+    Round 4: no elementwise kernels beside the GEMMs.  A branch layer's input cat[h, e] is a row of ONE buffer per branch
+    whose embedding columns are filled once, and each layer's GEMM writes its output straight into the next layer's h
+    columns (the last one into the trunk's input): no torch.cat.  Activations (forward) and their derivatives (backward: the
+    grad-input GEMM of the layer above multiplies by this layer's act') run in the GEMM epilogues, the bias gradient is a
+    row sum the grad-weight GEMM takes along, and strided views replace the .contiguous() copies (ns_gemm_fused)."""
 
     @staticmethod
     def forward(ctx, o: Tensor, d: Tensor, near: float, far: float, radius: float, n: int, *params: Tensor):
@@ -193,25 +242,41 @@ class DepthNetFunction(torch.autograd.Function):
         e_o, e_d = ops.posenc(o, 10), ops.posenc(d, 10)
         _, P = ops.sphere_intersect(o, d, radius)
         e_x = ops.posenc(P.reshape(-1, 6), 10)
-        saved_in: List[Tensor] = []
-
-        def branch(first, e):
-            h = e
-            for i in range(n):
-                inp = torch.cat([h, e], -1)
-                saved_in.append(inp)
-                h = linear_forward(inp, W_[first + i], B_[first + i])
-            return h
-
-        h_o, h_d, h_x = branch(0, e_o), branch(n, e_d), branch(2 * n, e_x)
-        y = torch.cat([h_o, h_d, h_x, e_o, e_d, e_x], -1)
+        M, width, dev = o.shape[0], W_[0].shape[0], o.device
+        embs = (e_o, e_d, e_x)
+        Es = [e.shape[1] for e in embs]
+        # trunk input: cat[h_o, h_d, h_x, e_o, e_d, e_x]; the branches write their last layer into the h columns
+        y0 = torch.empty((M, 3 * width + sum(Es)), dtype=torch.float32, device=dev)
+        col = 3 * width
+        for e, E in zip(embs, Es):
+            y0[:, col : col + E] = e
+            col += E
+        saved_in: List[Optional[Tensor]] = [None] * (3 * n)
+        bufs, inp = [], []
+        for b, (e, E) in enumerate(zip(embs, Es)):
+            inp.append(torch.cat([e, e], -1))                           # layer 0 sees cat[h = e, e]
+            bufs.append(torch.empty((max(n - 1, 1), M, width + E), dtype=torch.float32, device=dev))   # inputs of layers 1 .. n-1
+            if n > 1:
+                bufs[b][:, :, width:] = e                               # one broadcast copy: the e columns of every layer
+        for i in range(n):                                              # layer i of the three branches in ONE launch
+            probs = []
+            for b in range(3):
+                x, Wt = inp[b], W_[b * n + i]
+                saved_in[b * n + i] = x
+                out = y0[:, b * width : (b + 1) * width] if i == n - 1 else bufs[b][i][:, :width]
+                probs.append(dict(A=x, sa0=x.stride(0), sa1=1, B=Wt, sb0=Wt.shape[1], sb1=1, bias=B_[b * n + i], M=M, N=width,
+                                  K=x.shape[1], out=out))
+                if i < n - 1:
+                    inp[b] = bufs[b][i]
+            _gemm_batched(probs)
+        y = y0
         trunk_io = []
         for i in range(n):
-            out = linear_forward(y, W_[3 * n + i], B_[3 * n + i], LEAKY)
+            out = _gemm(y, y.stride(0), 1, W_[3 * n + i], W_[3 * n + i].shape[1], 1, B_[3 * n + i], M, width, y.shape[1], act=LEAKY)
             trunk_io.append((y, out))
             y = out
-        s = linear_forward(y, W_[4 * n], B_[4 * n], SIGMOID)
-        ctx.n, ctx.scale, ctx.width = n, float(far) - float(near), W_[0].shape[0]
+        s = _gemm(y, y.stride(0), 1, W_[4 * n], W_[4 * n].shape[1], 1, B_[4 * n], M, 1, width, act=SIGMOID)
+        ctx.n, ctx.scale, ctx.width = n, float(far) - float(near), width
         ctx.saved_in, ctx.trunk_io, ctx.last, ctx.s = saved_in, trunk_io, y, s
         ctx.weights = W_
         return near * (1 - s) + far * s                      # depth_net.py:168
@@ -220,23 +285,51 @@ class DepthNetFunction(torch.autograd.Function):
     def backward(ctx, dz: Tensor):
         n, W_, width = ctx.n, ctx.weights, ctx.width
         grads: List[Optional[Tensor]] = [None] * (2 * (4 * n + 1))
+        dev = ctx.s.device
+
+        def weight_grads(slot, dy, x):
+            """dW = dy^T x [N, K] and db = column sums of dy (the row sums of A = dy^T) in ONE launch"""
+            M_, N_, K_ = dy.shape[0], dy.shape[1], x.shape[1]
+            db = torch.empty((N_,), dtype=torch.float32, device=dev)
+            dW = _gemm(dy, 1, dy.stride(0), x, 1, x.stride(0), None, N_, K_, M_, a_rowsum=db)
+            grads[2 * slot], grads[2 * slot + 1] = dW, db
+
         g = _dev(dz, "dz") * ctx.scale
         act_backward_(g, ctx.s, SIGMOID)
-        grads[2 * 4 * n], grads[2 * 4 * n + 1] = linear_backward_weight(g, ctx.last)
-        d_y = linear_backward_input(g, W_[4 * n])
+        weight_grads(4 * n, g, ctx.last)
+        # d(trunk output n-1) = (g W_head) * leaky'(out_{n-1})
+        Wh = W_[4 * n]
+        d_y = _gemm(g, g.stride(0), 1, Wh, 1, Wh.shape[1], None, g.shape[0], width, 1, dact=LEAKY, dact_ref=ctx.trunk_io[n - 1][1])
         for i in range(n - 1, -1, -1):
-            y_in, y_out = ctx.trunk_io[i]
-            act_backward_(d_y, y_out, LEAKY)
-            grads[2 * (3 * n + i)], grads[2 * (3 * n + i) + 1] = linear_backward_weight(d_y, y_in)
-            # below trunk layer 0 only the three branch outputs (first 3*width columns) need a gradient
-            d_y = linear_backward_input(d_y, W_[3 * n + i], n_cols=None if i > 0 else 3 * width)
-        for b, first in enumerate((0, n, 2 * n)):
-            d_h = d_y[:, b * width : (b + 1) * width].contiguous()
-            for i in range(n - 1, -1, -1):
-                inp = ctx.saved_in[first + i]
-                grads[2 * (first + i)], grads[2 * (first + i) + 1] = linear_backward_weight(d_h, inp)
-                if i > 0:
-                    d_h = linear_backward_input(d_h, W_[first + i], n_cols=width)
+            y_in, _y_out = ctx.trunk_io[i]
+            weight_grads(3 * n + i, d_y, y_in)
+            Wi = W_[3 * n + i]
+            if i > 0:      # through the trunk layer below and ITS activation
+                d_y = _gemm(d_y, d_y.stride(0), 1, Wi, 1, Wi.shape[1], None, d_y.shape[0], width, width, dact=LEAKY,
+                            dact_ref=ctx.trunk_io[i - 1][1])
+            else:          # below trunk layer 0 only the three (affine) branch outputs need a gradient
+                d_y = _gemm(d_y, d_y.stride(0), 1, Wi, 1, Wi.shape[1], None, d_y.shape[0], 3 * width, width)
+        d_h = [d_y[:, b * width : (b + 1) * width] for b in range(3)]   # strided views: no copies
+        M = d_y.shape[0]
+        for i in range(n - 1, -1, -1):                                  # layer i of the three branches: two launches
+            probs = []
+            for b in range(3):
+                x = ctx.saved_in[b * n + i]
+                db = torch.empty((width,), dtype=torch.float32, device=dev)
+                dW = torch.empty((width, x.shape[1]), dtype=torch.float32, device=dev)
+                grads[2 * (b * n + i)], grads[2 * (b * n + i) + 1] = dW, db
+                probs.append(dict(A=d_h[b], sa0=1, sa1=d_h[b].stride(0), B=x, sb0=1, sb1=x.stride(0), M=width, N=x.shape[1], K=M,
+                                  out=dW, a_rowsum=db))
+            _gemm_batched(probs)
+            if i > 0:
+                probs, nxt = [], []
+                for b in range(3):
+                    Wi = W_[b * n + i]
+                    out = torch.empty((M, width), dtype=torch.float32, device=dev)
+                    nxt.append(out)
+                    probs.append(dict(A=d_h[b], sa0=d_h[b].stride(0), sa1=1, B=Wi, sb0=1, sb1=Wi.shape[1], M=M, N=width, K=width, out=out))
+                _gemm_batched(probs)
+                d_h = nxt
         return (None, None, None, None, None, None, *grads)
 
 

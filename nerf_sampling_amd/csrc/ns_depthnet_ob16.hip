@@ -13,6 +13,8 @@
 
 #include "ns_ob16_asm.inc"
 
+#include <type_traits>
+
 namespace {
 
 using namespace nsmlp;
@@ -148,27 +150,39 @@ depthnet_ob16_kernel(Depth16Args a) {
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
 
     if constexpr (PROD) {
-      static_assert(T == 4 && NKB == 8 && kInKB == 8 && NWAVES == 4, "the generated streams are W = 256, four tiles, four waves");
+      constexpr bool SPLIT = std::is_same<M, Mma16F16x3>::value;   // (hi, lo) blocks: two tiles fill the registers four plain tiles do
+      constexpr int NT = 4;                                        // 8-K-block register tuples per activation set
+      static_assert(T == (SPLIT ? 2 : 4) && NKB == 8 && kInKB == 8 && NWAVES == 4, "the generated streams are W = 256, four waves");
       prefetch(grp + gridDim.x);   // before the first statement: compiled code between two statements costs register copies
-      u32x4 A[8 * T], V[8 * T];
+      u32x4 A[8 * NT], V[8 * NT];
       static_for<T>([&](auto t_) {
         static_for<kInKB>([&](auto kb_) {
-          V[8 * decltype(t_)::value + decltype(kb_)::value] = __builtin_bit_cast(u32x4, e[decltype(t_)::value][decltype(kb_)::value].v);
+          constexpr int t = decltype(t_)::value, kb = decltype(kb_)::value;
+          if constexpr (SPLIT) {
+            V[2 * (8 * t + kb)] = __builtin_bit_cast(u32x4, e[t][kb].hi); V[2 * (8 * t + kb) + 1] = __builtin_bit_cast(u32x4, e[t][kb].lo);
+          } else {
+            V[8 * t + kb] = __builtin_bit_cast(u32x4, e[t][kb].v);
+          }
         });
       });
-      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 0 (folded input layer): V -> A
-      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 1: A -> V
-      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 2
-      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 3
-      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 4
-      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 5
-      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 6
-      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 7
-      hidden_leaky_asm_run<M, T, false>(ring, bias, g, A, V); bias += NSB * 16;   // 8
-      hidden_leaky_asm_run<M, T, true>(ring, bias, g, A, V); bias += NSB * 16;    // 9: the trunk's output is set V
+      hidden_leaky_asm_run<M, NT, false>(ring, bias, g, A, V); bias += NSB * 16;   // 0 (folded input layer): V -> A
+      hidden_leaky_asm_run<M, NT, true>(ring, bias, g, A, V); bias += NSB * 16;    // 1: A -> V
+      hidden_leaky_asm_run<M, NT, false>(ring, bias, g, A, V); bias += NSB * 16;   // 2
+      hidden_leaky_asm_run<M, NT, true>(ring, bias, g, A, V); bias += NSB * 16;    // 3
+      hidden_leaky_asm_run<M, NT, false>(ring, bias, g, A, V); bias += NSB * 16;   // 4
+      hidden_leaky_asm_run<M, NT, true>(ring, bias, g, A, V); bias += NSB * 16;    // 5
+      hidden_leaky_asm_run<M, NT, false>(ring, bias, g, A, V); bias += NSB * 16;   // 6
+      hidden_leaky_asm_run<M, NT, true>(ring, bias, g, A, V); bias += NSB * 16;    // 7
+      hidden_leaky_asm_run<M, NT, false>(ring, bias, g, A, V); bias += NSB * 16;   // 8
+      hidden_leaky_asm_run<M, NT, true>(ring, bias, g, A, V); bias += NSB * 16;    // 9: the trunk's output is set V
       static_for<T>([&](auto t_) {
         static_for<NKB>([&](auto kb_) {
-          hB[decltype(t_)::value][decltype(kb_)::value].v = __builtin_bit_cast(typename M::AFrag, V[8 * decltype(t_)::value + decltype(kb_)::value]);
+          constexpr int t = decltype(t_)::value, kb = decltype(kb_)::value;
+          if constexpr (SPLIT) {
+            hB[t][kb].hi = __builtin_bit_cast(f16x8, V[2 * (8 * t + kb)]); hB[t][kb].lo = __builtin_bit_cast(f16x8, V[2 * (8 * t + kb) + 1]);
+          } else {
+            hB[t][kb].v = __builtin_bit_cast(typename M::AFrag, V[8 * t + kb]);
+          }
         });
       });
       E::template layer<1, NKB, kNone>(ring, bias, g, hA, last, in_B);
@@ -255,6 +269,9 @@ int ns_depthnet_forward_ob16(const ns_weights* net, const float* o_dev, const fl
       return launch<Plain16<Mma16F16>, 8, true>(a, stream);
     return wide ? launch<Plain16<Mma16F16>, 8>(a, stream) : launch<Plain16<Mma16F16>, 4>(a, stream);
   }
-  if (net->dtype == NS_DTYPE_F16X3) return wide ? launch<Split16, 8>(a, stream) : launch<Split16, 4>(a, stream);
+  if (net->dtype == NS_DTYPE_F16X3) {
+    if (wide && net->depth == 10 && !ns::debug_flags().generic_kernels) return launch<Split16, 8, true>(a, stream);
+    return wide ? launch<Split16, 8>(a, stream) : launch<Split16, 4>(a, stream);
+  }
   return NS_E_UNSUPPORTED;
 }

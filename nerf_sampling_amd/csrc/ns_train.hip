@@ -17,12 +17,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // (r, h) feeds row r with the k values 8q + 4h + m, m = 0..3, of its slice: no LDS staging, no barrier in the K
 // loop, all loads of a slice in flight at once), and the four partial tiles are summed through LDS in a fixed
 // order (deterministic).  v_mfma_f32_32x32x2_f32: exact fp32 products.
-template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ void __launch_bounds__(256)
-gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const float* __restrict__ B,
-                    int64_t sb0, int64_t sb1, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
-                    int M, int N, int K, int accumulate) {
+//
+// Epilogues (round 4: a training step was ~360 launches, a third of them 5-us elementwise / reduction kernels around the
+// GEMMs): `act` applies an activation to the result (forward layers); `dact` multiplies the result by the derivative of the
+// activation whose OUTPUT is dref (the grad-input GEMM of the layer above does the backward through this layer's
+// activation); `a_rowsum` receives sum_k A[i, k] from the workgroups of the first output column -- with A = dy^T that is
+// the bias gradient, which the grad-weight GEMM reads anyway.
+struct GemmEpilogue {
+  int act;                 // 0 none, 1 relu, 2 leaky(0.01), 3 sigmoid: C = act(acc + bias)
+  int dact;                // 0 none, else C = acc * act'(.) of activation `dact`, evaluated from its output dref[i, j]
+  const float* dref;
+  int64_t ld_ref;
+  float* a_rowsum;         // [M] or null
+};
+
+// KT: k values per trip of a wave (32 or 64).  The kernel is bound by the CHAIN of trips -- each one a global-load round
+// trip, ~1.5 us -- not by bandwidth or MFMAs: with 64 the grad-weight GEMMs (K = 1024 rows, 256 per wave) take 4 trips
+// instead of 8.  Same MFMA order per accumulator, so the results do not depend on KT.
+template <bool A_KCONTIG, bool B_KCONTIG, int KT>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, int64_t sa0, int64_t sa1, const float* __restrict__ B,
+                                          int64_t sb0, int64_t sb1, const float* __restrict__ bias, float* __restrict__ C,
+                                          int64_t ldc, int M, int N, int K, int accumulate, const GemmEpilogue& ep) {
   __shared__ float red[4][16][64];
+  __shared__ float asum_s[4][64];
+  float asum = 0.f;
+  const bool want_rowsum = ep.a_rowsum != nullptr && blockIdx.x == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -35,11 +54,12 @@ gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  // 32 k per trip: 16 + 16 independent loads in flight, then 16 MFMAs
-  for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    float a[16], b[16];
+  // KT k per trip: KT / 2 + KT / 2 independent loads in flight, then KT / 2 MFMAs
+  constexpr int NE = KT / 2;
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
+    float a[NE], b[NE];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < KT / 8; ++c)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         const int k = k0 + 8 * c + 4 * h + m;
@@ -48,8 +68,13 @@ gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const
         b[4 * c + m] = (jok && kok) ? bp[B_KCONTIG ? k : k * sb1] : 0.f;
       }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    for (int e = 0; e < NE; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+    if (want_rowsum) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) asum += a[e];
+    }
   }
+  if (want_rowsum) asum_s[wave][lane] = asum;
 #pragma unroll
   for (int q = 0; q < 16; ++q) red[wave][q][lane] = acc[q];
   __syncthreads();
@@ -62,9 +87,48 @@ gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const
       float v = (red[0][q][lane] + red[1][q][lane]) + (red[2][q][lane] + red[3][q][lane]);
       if (bias) v += bias[j];
       float* c = C + static_cast<int64_t>(row) * ldc + j;
-      *c = accumulate ? *c + v : v;
+      if (accumulate) v += *c;
+      if (ep.act == 1) v = fmaxf(v, 0.f);
+      else if (ep.act == 2) v = v > 0.f ? v : 0.01f * v;
+      else if (ep.act == 3) v = 1.f / (1.f + expf(-v));
+      if (ep.dact) {
+        const float y = ep.dref[static_cast<int64_t>(row) * ep.ld_ref + j];
+        v *= ep.dact == 1 ? (y > 0.f ? 1.f : 0.f) : ep.dact == 2 ? (y > 0.f ? 1.f : 0.01f) : y * (1.f - y);
+      }
+      *c = v;
     }
   }
+  // row sums of A (fixed order: the two k-halves of each wave, waves 0..3), one thread per row of the tile
+  if (want_rowsum && threadIdx.x < 32 && i0 + static_cast<int>(threadIdx.x) < M) {
+    const int rr = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += asum_s[w][rr] + asum_s[w][rr + 32];
+    ep.a_rowsum[i0 + rr] = t;
+  }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int KT = 32>
+__global__ void __launch_bounds__(256)
+gemm_strided_kernel(const float* __restrict__ A, int64_t sa0, int64_t sa1, const float* __restrict__ B,
+                    int64_t sb0, int64_t sb1, const float* __restrict__ bias, float* __restrict__ C, int64_t ldc,
+                    int M, int N, int K, int accumulate, GemmEpilogue ep) {
+  gemm_tile<A_KCONTIG, B_KCONTIG, KT>(A, sa0, sa1, B, sb0, sb1, bias, C, ldc, M, N, K, accumulate, ep);
+}
+
+// Up to four GEMMs of the same kind in ONE launch (blockIdx.z picks the problem; the grid covers the largest): the three skip
+// branches of the DepthNet run the same layer shape side by side, and a training step is bound by its launch count.
+struct GemmBatch {
+  ns_gemm_problem p[4];
+};
+template <bool A_KCONTIG, bool B_KCONTIG, int KT>
+__global__ void __launch_bounds__(256)
+gemm_batched_kernel(GemmBatch batch) {
+  const ns_gemm_problem& q = batch.p[blockIdx.z];
+  if (static_cast<int>(blockIdx.x) * 32 >= q.N || static_cast<int>(blockIdx.y) * 32 >= q.M) return;   // (workgroup-uniform)
+  const GemmEpilogue ep{q.act, q.dact, q.dact_ref_dev, q.ld_ref, q.a_rowsum_dev};
+  gemm_tile<A_KCONTIG, B_KCONTIG, KT>(q.A_dev, q.sa0, q.sa1, q.B_dev, q.sb0, q.sb1, q.bias_dev, q.C_dev, q.ldc, q.M, q.N, q.K,
+                                      q.accumulate, ep);
 }
 
 // column sums: out[j] = sum_i X[i*ld + j]   (bias gradient).  Block = 32 columns x 32 row lanes; coalesced
@@ -193,18 +257,65 @@ extern "C" {
 int ns_gemm_strided(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0, int64_t sb1,
                     const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K, int accumulate,
                     void* stream) {
+  return ns_gemm_fused(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, C_dev, ldc, M, N, K, accumulate, 0, 0, nullptr, 0,
+                       nullptr, stream);
+}
+
+int ns_gemm_fused(const float* A_dev, int64_t sa0, int64_t sa1, const float* B_dev, int64_t sb0, int64_t sb1,
+                  const float* bias_dev, float* C_dev, int64_t ldc, int M, int N, int K, int accumulate, int act,
+                  int dact, const float* dact_ref_dev, int64_t ld_ref, float* a_rowsum_dev, void* stream) {
   NS_REQUIRE(M >= 0 && N >= 0 && K >= 0, "bad shape");
+  NS_REQUIRE(act >= 0 && act <= 3 && dact >= 0 && dact <= 3 && (dact == 0 || dact_ref_dev), "bad epilogue");
   if (M == 0 || N == 0) return NS_OK;
   NS_REQUIRE(A_dev && B_dev && C_dev, "null pointer");
   dim3 grid((N + 31) / 32, (M + 31) / 32);
   hipStream_t s = ns::as_stream(stream);
-#define NS_GEMM(AK, BK) gemm_strided_kernel<AK, BK><<<grid, 256, 0, s>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, \
-                                                                        C_dev, ldc, M, N, K, accumulate)
+  const GemmEpilogue ep{act, dact, dact_ref_dev, ld_ref, a_rowsum_dev};
+  const bool wide = K >= 256;      // >= 64 k per wave: trips of 64
+#define NS_GEMM(AK, BK)                                                                                                  \
+  do {                                                                                                                   \
+    if (wide) gemm_strided_kernel<AK, BK, 64><<<grid, 256, 0, s>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, C_dev, ldc, \
+                                                                   M, N, K, accumulate, ep);                               \
+    else gemm_strided_kernel<AK, BK, 32><<<grid, 256, 0, s>>>(A_dev, sa0, sa1, B_dev, sb0, sb1, bias_dev, C_dev, ldc, M,   \
+                                                              N, K, accumulate, ep);                                       \
+  } while (0)
   if (sa1 == 1 && sb1 == 1) NS_GEMM(true, true);
   else if (sa1 == 1) NS_GEMM(true, false);
   else if (sb1 == 1) NS_GEMM(false, true);
   else NS_GEMM(false, false);
 #undef NS_GEMM
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_gemm_fused_batched(const ns_gemm_problem* problems_host, int count, void* stream) {
+  NS_REQUIRE(problems_host && count >= 1 && count <= 4, "1 to 4 problems per launch");
+  GemmBatch batch{};
+  int gx = 0, gy = 0, kmax = 0;
+  const bool ak = problems_host[0].sa1 == 1, bk = problems_host[0].sb1 == 1;
+  for (int b = 0; b < count; ++b) {
+    const ns_gemm_problem& q = problems_host[b];
+    NS_REQUIRE(q.M >= 1 && q.N >= 1 && q.K >= 0 && q.A_dev && q.B_dev && q.C_dev, "bad problem");
+    NS_REQUIRE(q.act >= 0 && q.act <= 3 && q.dact >= 0 && q.dact <= 3 && (q.dact == 0 || q.dact_ref_dev), "bad epilogue");
+    NS_REQUIRE((q.sa1 == 1) == ak && (q.sb1 == 1) == bk, "the problems of one launch share their operand layout (k-contiguous or not)");
+    batch.p[b] = q;
+    gx = gx > (q.N + 31) / 32 ? gx : (q.N + 31) / 32;
+    gy = gy > (q.M + 31) / 32 ? gy : (q.M + 31) / 32;
+    kmax = kmax > q.K ? kmax : q.K;
+  }
+  dim3 grid(gx, gy, count);
+  hipStream_t s = ns::as_stream(stream);
+  const bool wide = kmax >= 256;
+#define NS_GEMMB(AK, BK)                                                             \
+  do {                                                                               \
+    if (wide) gemm_batched_kernel<AK, BK, 64><<<grid, 256, 0, s>>>(batch);           \
+    else gemm_batched_kernel<AK, BK, 32><<<grid, 256, 0, s>>>(batch);                \
+  } while (0)
+  if (ak && bk) NS_GEMMB(true, true);
+  else if (ak) NS_GEMMB(true, false);
+  else if (bk) NS_GEMMB(false, true);
+  else NS_GEMMB(false, false);
+#undef NS_GEMMB
   NS_LAUNCH_CHECK();
   return NS_OK;
 }

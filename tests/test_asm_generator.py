@@ -88,16 +88,41 @@ def test_special_layer_streams(gen, tiles):
 @pytest.mark.parametrize("skip", [False, True])
 def test_split_operand_stream_shape(gen, in_a, skip):
     """f16x3: per K-block a W_hi chunk (x_hi and x_lo of both tiles) and a W_lo chunk (x_hi only): three MFMAs per product
-    term; ten (twelve with the AGPR writes) VALU instructions per converted dword pair"""
+    term; seven (nine with the AGPR writes) VALU instructions per converted dword pair: NaN-keeping ReLU by compare + select,
+    one v_cvt_pk for the two fp16 hi halves, one mixed-precision fma per fp16 remainder"""
     e, slabs = gen.gen_layer_x3(in_a, skip)
     nkb = 10 if skip else 8
     kinds = [i.kind for i in e.ins]
     assert slabs == 2 * nkb and kinds.count("mfma") == 16 * nkb * 6 and kinds.count("lds") == 16 * 2 * nkb + 16
     valu = [i.text.split()[0] for i in e.ins if i.kind == "valu"]
     pairs = 16 * 4                                    # sub-blocks x (two tiles x two dword pairs)
-    assert valu.count("v_cvt_pk_f16_f32") == 2 * pairs and valu.count("v_cmp_ngt_f32_e32") == 2 * pairs
-    assert valu.count("v_sub_f32_e32") == 2 * pairs and valu.count("v_accvgpr_write_b32") == (0 if in_a else 2 * pairs)
+    assert valu.count("v_cvt_pk_f16_f32") == pairs and valu.count("v_cmp_ngt_f32_e32") == 2 * pairs
+    assert valu.count("v_fma_mixlo_f16") == pairs and valu.count("v_fma_mixhi_f16") == pairs and valu.count("v_sub_f32_e32") == 0
+    assert valu.count("v_accvgpr_write_b32") == (0 if in_a else 2 * pairs)
+    assert len(valu) - valu.count("v_lshl_add_u32") == pairs * (7 if in_a else 9)
     gen.check(e.ins)
+    if not skip:      # the DepthNet's variant: LeakyReLU on the fp32 values instead of the ReLU, same count
+        e2, slabs2 = gen.gen_layer_x3(in_a, False, act="leaky")
+        valu2 = [i.text.split()[0] for i in e2.ins if i.kind == "valu"]
+        assert slabs2 == slabs and valu2.count("v_mul_f32_e32") == 2 * pairs and valu2.count("v_max_f32_e32") == 2 * pairs
+        assert valu2.count("v_cmp_ngt_f32_e32") == 0 and len(valu2) == len(valu)
+        gen.check(e2.ins)
+
+
+@pytest.mark.parametrize("in_a", [True, False])
+def test_leaky_stream_shape(gen, in_a):
+    """the DepthNet's fp16 hidden layers: LeakyReLU(0.01) on the packed value, one more pipeline stage (v_pk_mul_f16 by the
+    slope operand, v_pk_max_f16) than the ReLU streams, same MFMAs and ring protocol"""
+    e, slabs = gen.gen_layer("f16", in_a, False, act="leaky")
+    kinds = [i.kind for i in e.ins]
+    assert slabs == 8 and kinds.count("mfma") == 4 * 16 * 8 and kinds.count("dma") == 4 * slabs
+    valu = [i.text.split()[0] for i in e.ins if i.kind == "valu"]
+    assert valu.count("v_cvt_pk_f16_f32") == 128 and valu.count("v_pk_mul_f16") == 128 and valu.count("v_pk_max_f16") == 128
+    assert valu.count("v_pk_max_i16") == 0 and valu.count("v_accvgpr_write_b32") == (0 if in_a else 128)
+    assert all("%[slope]" in i.text for i in e.ins if i.text.startswith("v_pk_mul_f16"))
+    gen.check(e.ins)
+    with pytest.raises(AssertionError):
+        gen.gen_layer("bf16", in_a, False, act="leaky")          # no packed bf16 multiply on gfx950
 
 
 def test_checker_rejects_broken_streams(gen):

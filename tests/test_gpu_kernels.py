@@ -320,15 +320,18 @@ def test_hand_scheduled_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_m
                     assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (dtype, tiles, R, N, (got - ref).abs().max().item())
 
 
-def test_depthnet_generated_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules):
-    """The production DepthNet (10 x 256 trunk, fp16 operands -- what the bf16 compute dtype pairs the field with) runs its ten
-    LeakyReLU layers as generated streams (tools/gen_ob16_asm.py, act = "leaky"); the switch generic_kernels sends the same
-    call through the compiled layers, which apply the same packed v_pk_mul_f16 / v_pk_max_f16 LeakyReLU: depths must agree bit
-    for bit.  Ragged ray counts, several groups per workgroup; rays that miss the sphere (NaN) included."""
+@pytest.mark.parametrize("dtype", ["f16", "f16x3"])
+def test_depthnet_generated_layers_are_bit_identical_to_the_compiled_ones(ops, gpu_modules, dtype):
+    """The production DepthNet (10 x 256 trunk) on fp16 operands -- what the bf16 compute dtype pairs the field with -- and on
+    split fp16 operands (the PSNR guard's DepthNet) runs its ten LeakyReLU layers as generated streams (tools/gen_ob16_asm.py,
+    act = "leaky"); the switch generic_kernels sends the same call through the compiled layers (fp16: the same packed
+    v_pk_mul_f16 / v_pk_max_f16 LeakyReLU; f16x3: the same fp32 max and the same hi / lo split, whose remainder the streams
+    form with one mixed-precision fma): depths must agree bit for bit.  Ragged ray counts, several groups per workgroup; rays
+    that miss the sphere (NaN) included."""
     m = gpu_modules("lego_synth")
     dn = m["depth"]
     assert list(dn.cat_hidden_sizes) == [256] * 10
-    packed = dn.packed("f16")
+    packed = dn.packed(dtype)
     gen = torch.Generator().manual_seed(17)
     for R in (1, 77, 4096, 70001):
         o = (torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1) * 4.0).cuda()

@@ -379,3 +379,56 @@ def test_hip_adam_reloads_its_state_in_device_step_mode(gpu_modules):
         opt.step(); ref.step()
         assert torch.allclose(w, ref_w, rtol=0, atol=1e-6), float((w - ref_w).abs().max())       # (an update is ~2e-3)
         assert float(opt.state_dict()["state"][0]["step"]) == 4.0
+
+
+@pytest.mark.parametrize("use_viewdirs,skips", [(True, [4]), (False, [2]), (False, [])])
+def test_nerf_input_gradient_both_heads(use_viewdirs, skips):
+    """autograd.NerfInputGrad (the frozen field's gradient w.r.t. its input points, Trainer.py:506-544 via nerf_utils.py:692-715)
+    for both heads of the reference's NeRF -- alpha / feature / views / rgb with view directions, output_linear without
+    (run_nerf_helpers.py:119-133) -- against torch-CPU autograd of the oracle's forward on the same weights."""
+    from nerf_sampling_amd import ops
+    from nerf_sampling_amd.autograd import NerfInputGrad
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+    ops.set_compute_dtype("f32")
+    torch.manual_seed(3)
+    D, W = 6, 128
+    net = NeRF(D=D, W=W, input_ch=63, input_ch_views=27 if use_viewdirs else 0, output_ch=5, skips=skips, use_viewdirs=use_viewdirs)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.5)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    R, N = 37, 5
+    pts = ((torch.rand(R, N, 3) * 2 - 1) * 1.5)
+    view = torch.nn.functional.normalize(torch.randn(R, 3), dim=-1)
+    C = 4 if use_viewdirs else 5
+    gout = torch.randn(R, N, C)
+    # reference: plain torch on the CPU
+    p_cpu = pts.clone().requires_grad_(True)
+    x = O.posenc(p_cpu.reshape(-1, 3), 10)
+    h = x
+    for i in range(D):
+        h = torch.relu(torch.nn.functional.linear(h, params[f"pts_linears.{i}.weight"], params[f"pts_linears.{i}.bias"]))
+        if i in skips:
+            h = torch.cat([x, h], -1)
+    if use_viewdirs:
+        v = O.posenc(view[:, None].expand(R, N, 3).reshape(-1, 3), 4)
+        sigma = torch.nn.functional.linear(h, params["alpha_linear.weight"], params["alpha_linear.bias"])
+        feat = torch.nn.functional.linear(h, params["feature_linear.weight"], params["feature_linear.bias"])
+        hv = torch.relu(torch.nn.functional.linear(torch.cat([feat, v], -1), params["views_linears.0.weight"], params["views_linears.0.bias"]))
+        raw_ref = torch.cat([torch.nn.functional.linear(hv, params["rgb_linear.weight"], params["rgb_linear.bias"]), sigma], -1)
+    else:
+        raw_ref = torch.nn.functional.linear(h, params["output_linear.weight"], params["output_linear.bias"])
+    (raw_ref.reshape(R, N, C) * gout).sum().backward()
+    # build
+    p_dev = pts.cuda().requires_grad_(True)
+    raw = NerfInputGrad.apply(p_dev, view.cuda() if use_viewdirs else None, net)
+    assert raw.shape == (R, N, C)
+    scale = raw_ref.abs().max()
+    assert float((raw.detach().cpu().reshape(-1, C) - raw_ref.detach()).abs().max() / scale) < 2e-5
+    (raw * gout.cuda()).sum().backward()
+    gs = p_cpu.grad.abs().max()
+    assert float((p_dev.grad.cpu() - p_cpu.grad).abs().max() / gs) < 2e-4, float((p_dev.grad.cpu() - p_cpu.grad).abs().max() / gs)

@@ -178,7 +178,7 @@ def test_depthnet16_kernels_use_no_scratch_and_no_full_dma_wait():
     """The folded DepthNet on the same engine: bf16, f16 and split-f16 (f16x3), W = 256 and 128 -- no scratch (round 1's
     kernel spilled 91 VGPRs and kept a 655 MB global stash), no compiler-inserted full DMA wait in the slab loop."""
     dis, notes = _isa_of(b"depthnet_ob16_kernel")
-    _check_mlp_kernels(dis, notes, "depthnet_ob16_kernel", 7, "v_mfma_f32_16x16x32", 500)
+    _check_mlp_kernels(dis, notes, "depthnet_ob16_kernel", 8, "v_mfma_f32_16x16x32", 500)
 
 
 def test_depthnet_production_kernel_is_straight_line_generated_code():

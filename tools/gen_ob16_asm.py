@@ -803,14 +803,18 @@ template <> struct SpecialAsm<{mname}, {nt}, {kid}> {{
 """
 
 
-def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
+def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8, act="relu"):
     """One hidden layer of the split-operand kernel (f16x3: x = hi + lo in fp16, three MFMAs per product term), T = 2
     tiles: layer_ob16x3<> + convert_last16x3<> of ns_mlp_engine.h as one statement.  A sub-block is 2 nkb chunks: chunk
     2 kc is W_hi of K-block kc (MFMAs on x_hi and x_lo of both tiles), chunk 2 kc + 1 is W_lo (x_hi only).  Same register
     map as the 16-bit layers with (hi, lo) tuple pairs: set element [tile][kb][half] = base + 64 tile + 8 kb + 4 half;
-    accumulators v[0:15], conversion scratch v[16:31].  A finished dword pair costs ten VALU instructions (NaN-keeping
-    ReLU by compare + select, fp16 hi, its fp32 image, the remainder, fp16 lo), twelve with the AGPR writes; they are
-    queued per sub-block and issued one or two per MFMA gap of the following sub-block."""
+    accumulators v[0:15], conversion scratch v[16:31].  A finished dword pair costs SEVEN VALU instructions (round 4; ten
+    before): the NaN-keeping ReLU by compare + select (4), fp16 hi of both (v_cvt_pk_f16_f32), and the fp16 remainders
+    lo = fp16(x - hi) as ONE mixed-precision fma each -- v_fma_mixlo_f16 / v_fma_mixhi_f16 compute fma(f32(hi), -1, x) in fp32
+    (exact: hi is the nearest fp16) and round it to fp16 into one half of the destination, the same value the
+    convert-back / subtract / convert chain produced; nine with the AGPR writes.  act = "leaky" (the DepthNet): max(x, 0.01 x)
+    on the fp32 values instead of the ReLU (same count).  They are queued per sub-block and issued one or two per MFMA gap of
+    the following sub-block."""
     TX = 2
     nkb = nkb_h + (2 if skip else 0)
     cps = 2 * nkb
@@ -846,15 +850,19 @@ def gen_layer_x3(in_a, skip, nsb=16, nkb_h=8):
         dhi, dlo = R(ohi[0], ohi[1] + dw), R(olo[0], olo[1] + dw)
         H, L = (dhi, dlo) if in_a else (ht, lt)
         ops = []
-        for x in (a, b):                 # x < 0 ? 0 : x, NaN stays NaN (as torch.relu)
-            ops.append(lambda x=x: e.valu(f"v_cmp_ngt_f32_e32 vcc, 0, {fmt(x)}", (x,), ()))
-            ops.append(lambda x=x: e.valu(f"v_cndmask_b32_e32 {fmt(x)}, 0, {fmt(x)}, vcc", (x,), (x,)))
+        if act == "leaky":               # max(x, 0.01 x) on the fp32 values (NaN stays NaN), as convert_piece16x3<kLeaky>
+            for x, tmp in ((a, ba), (b, bb)):
+                ops.append(lambda x=x, tmp=tmp: e.valu(f"v_mul_f32_e32 {fmt(tmp)}, 0x3c23d70a, {fmt(x)}", (x,), (tmp,)))
+                ops.append(lambda x=x, tmp=tmp: e.valu(f"v_max_f32_e32 {fmt(x)}, {fmt(x)}, {fmt(tmp)}", (x, tmp), (x,)))
+        else:
+            for x in (a, b):             # x < 0 ? 0 : x, NaN stays NaN (as torch.relu)
+                ops.append(lambda x=x: e.valu(f"v_cmp_ngt_f32_e32 vcc, 0, {fmt(x)}", (x,), ()))
+                ops.append(lambda x=x: e.valu(f"v_cndmask_b32_e32 {fmt(x)}, 0, {fmt(x)}, vcc", (x,), (x,)))
         ops.append(lambda: e.valu(f"v_cvt_pk_f16_f32 {fmt(H)}, {fmt(a)}, {fmt(b)}", (a, b), (H,)))
-        ops.append(lambda: e.valu(f"v_cvt_f32_f16_e32 {fmt(ba)}, {fmt(H)}", (H,), (ba,)))
-        ops.append(lambda: e.valu(f"v_cvt_f32_f16_sdwa {fmt(bb)}, {fmt(H)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", (H,), (bb,)))
-        ops.append(lambda: e.valu(f"v_sub_f32_e32 {fmt(a)}, {fmt(a)}, {fmt(ba)}", (a, ba), (a,)))      # exact: hi is the nearest fp16
-        ops.append(lambda: e.valu(f"v_sub_f32_e32 {fmt(b)}, {fmt(b)}, {fmt(bb)}", (b, bb), (b,)))
-        ops.append(lambda: e.valu(f"v_cvt_pk_f16_f32 {fmt(L)}, {fmt(a)}, {fmt(b)}", (a, b), (L,)))
+        # lo = fp16(x - hi): one mixed-precision fma per element (src0 = the fp16 hi, low / high half; src1, src2 fp32);
+        # each writes one half of L and keeps the other, so L counts as read too
+        ops.append(lambda: e.valu(f"v_fma_mixlo_f16 {fmt(L)}, {fmt(H)}, -1.0, {fmt(a)} op_sel_hi:[1,0,0]", (H, a, L), (L,)))
+        ops.append(lambda: e.valu(f"v_fma_mixhi_f16 {fmt(L)}, {fmt(H)}, -1.0, {fmt(b)} op_sel:[1,0,0] op_sel_hi:[1,0,0]", (H, b, L), (L,)))
         if not in_a:
             ops.append(lambda: e.valu(f"v_accvgpr_write_b32 {fmt(dhi)}, {fmt(ht)}", (ht,), (dhi,)))
             ops.append(lambda: e.valu(f"v_accvgpr_write_b32 {fmt(dlo)}, {fmt(lt)}", (lt,), (dlo,)))
@@ -1163,6 +1171,12 @@ def main():
         name = f"f16 LeakyReLU {'A->V' if in_a else 'V->A'}"
         out.append(cpp_function(name, "f16", in_a, False, e, slabs, leaky=True))
         print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 1024), "
+              f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
+    for in_a in (True, False):           # the DepthNet's hidden layers on split operands (the PSNR guard's DepthNet)
+        e, slabs = gen_layer_x3(in_a, False, act="leaky")
+        name = f"f16x3 LeakyReLU {'A->V' if in_a else 'V->A'}"
+        out.append(cpp_function(name, "f16x3", in_a, False, e, slabs, leaky=True))
+        print(f"{name}: {len(e.ins)} instr, issue estimate {issue_cycles(e.ins) / slabs:.0f} cycles/slab (matrix pipe 768), "
               f"nops {sum(i.kind == 'nop' for i in e.ins)}, waits {sum(i.kind == 'wait' for i in e.ins)}", file=sys.stderr)
     for in_a in (True, False):
         for skip in (False, True):
