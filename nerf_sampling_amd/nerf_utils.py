@@ -339,6 +339,8 @@ def render_path(render_poses, hwf, K, chunk, render_kwargs, step, wandb_log=Fals
         prev = (i, rgb, disp, extras, sink)
     if prev is not None:
         consume(*prev)
+    global _held_sink
+    _held_sink = None                                    # (finished by consume(): nothing is left in flight)
     _sink_pool.clear()                                   # the pinned buffers go back to torch's cache
     drain_host_copies()
     if save_scene_data and savedir is not None:
