@@ -34,21 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-#ifndef NS_OB16_DMA_SPREAD
-#define NS_OB16_DMA_SPREAD 0   // 1: a wave's four DMA pieces of a slab are issued a quarter slab apart instead of all after the barrier
-#endif
-#ifndef NS_OB16_PAIR_LOADS
-#define NS_OB16_PAIR_LOADS 0   // 1: fragment reads issued in pairs every other chunk step (half the lgkmcnt waits, one chunk less read-ahead)
-#endif
-#ifndef NS_DMA_SADDR
-#define NS_DMA_SADDR 1         // 1: SGPR-base LDS-DMA, one M0 write per slab (each wave fetches consecutive chunks)
-#endif
-#ifndef NS_OB16_LATE_REFILL
-#define NS_OB16_LATE_REFILL 1  // 1: a chunk step refills the fragment register of the previous chunk (one chunk less read-ahead, no WAR nops)
-#endif
-#ifndef NS_OB16_BIAS_C
-#define NS_OB16_BIAS_C 0       // 1: the bias is the C operand of a sub-block's first MFMA (no per-tile copies into the accumulators)
-#endif
 
 constexpr int kChunkBytes = 1024;
 #ifndef NS_SLAB_CHUNKS
@@ -239,7 +224,6 @@ struct Pipe {
   // round trip of the slab it has just requested, three slabs early, and the ring prefetches nothing (measured:
   // MFMA pipe busy 52-69 % with it).  The asm form leaves the ordering to the counted wait + barrier of begin_slab().
   __device__ __forceinline__ void issue() {
-#if NS_DMA_SADDR
     // One M0 write per slab: wave w fetches the LPW CONSECUTIVE chunks w*LPW .. w*LPW+LPW-1 with the SGPR-base form of the
     // instruction (address = s[base] + 32-bit lane offset + immediate), the immediate offset stepping through both the
     // global and the LDS address.  Saves a 64-bit VALU add, an M0 write and its wait state per piece.
@@ -275,7 +259,6 @@ struct Pipe {
       issue_slot = next_slot(issue_slot);
       return;
     }
-#endif
     // wave-uniform part of the address in SGPRs, per-lane part a constant 32-bit offset (lane * 16)
     const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
     const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
@@ -284,49 +267,6 @@ struct Pipe {
     for (int i = 0; i < LPW; ++i) lds_dma16(src + i * NWAVES * kChunkBytes + lane_off, dst + i * NWAVES * kChunkBytes);
     issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
     issue_slot = next_slot(issue_slot);
-  }
-
-  // the same slab, one DMA instruction at a time (spread over the chunk steps of the open slab by stream_chunks<> when
-  // NS_OB16_DMA_SPREAD: the four waves' sixteen 1-KiB pieces then do not queue behind each other in the CU's memory
-  // pipeline right after the barrier); issue_advance() closes the slab
-  template <int I>
-  __device__ __forceinline__ void issue_piece() {
-    static_assert(I >= 0 && I < LPW, "piece index");
-    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * kChunkBytes;
-    const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * kChunkBytes;
-    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
-    lds_dma16(src + I * NWAVES * kChunkBytes + lane_off, dst + I * NWAVES * kChunkBytes);
-  }
-  // SGPR-base form of one piece (NS_OB16_DMA_SPREAD == 2): wave w owns the LPW consecutive chunks w*LPW .. of the slab
-  // being fetched; piece I is one instruction with immediate offset I KiB on both addresses.  M0 is rewritten in the
-  // same statement (the compiler does not preserve it between statements).
-  template <int I>
-  __device__ __forceinline__ void issue_piece_saddr() {
-    static_assert(I >= 0 && I < LPW && LPW * kChunkBytes <= 4096, "piece index");
-    const char* src = stream + static_cast<size_t>(issue_slab) * kSlabBytes + wave * (LPW * kChunkBytes);
-    const uint32_t dst = lds_off + issue_slot * kSlabBytes + wave * (LPW * kChunkBytes);
-    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
-    const uint32_t m0v = __builtin_amdgcn_readfirstlane(dst);
-    const uint64_t base = reinterpret_cast<uint64_t>(src);
-    const uint32_t blo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
-    const uint64_t sbase = (static_cast<uint64_t>(bhi) << 32) | blo;
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(m0v), "v"(lane_off), "s"(sbase), "n"(I * kChunkBytes) : "memory");
-  }
-  __device__ __forceinline__ void issue_advance() {
-    issue_slab = (issue_slab + 1 == n_slabs) ? 0u : issue_slab + 1;
-    issue_slot = next_slot(issue_slot);
-  }
-  // begin_slab() without the refill: the caller issues the LPW pieces itself and then issue_advance()
-  __device__ __forceinline__ void begin_slab_no_issue() {
-    wait_vm<(AHEAD - 2) * LPW>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    cur = lds_off + read_slot * kSlabBytes + lane * 16;
-    read_slot = next_slot(read_slot);
-    nxt = lds_off + read_slot * kSlabBytes + lane * 16;
   }
 
   // s_waitcnt vmcnt(N) alone (the other counters at "don't wait")
@@ -477,74 +417,18 @@ __device__ __forceinline__ void stream_chunks(PipeT& pipe, F&& op) {
     constexpr int s = decltype(s_)::value;
     constexpr int USED = (TOTAL - s * kSlabChunks) < kSlabChunks ? (TOTAL - s * kSlabChunks) : kSlabChunks;
     static_assert(USED % PipeT::kDepth == 0 && USED >= PipeT::kDepth, "fragment pipeline needs USED % depth == 0");
-#if NS_OB16_DMA_SPREAD == 2
-    constexpr int STRIDE = USED / PipeT::LPW > 0 ? USED / PipeT::LPW : 1;
-    pipe.begin_slab_no_issue();
-#elif NS_OB16_DMA_SPREAD
-    constexpr int STRIDE = USED / PipeT::LPW > 0 ? USED / PipeT::LPW : 1;
-    pipe.begin_slab_no_issue();
-    pipe.template issue_piece<0>();
-#else
     pipe.begin_slab();
-#endif
     static_for<USED>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
-#if NS_OB16_DMA_SPREAD == 1
-      if constexpr (p > 0 && p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece<p / STRIDE>();
-#endif
-      // NS_OB16_DMA_SPREAD == 2: this slab's refill pieces ride with the fragment read, i.e. they are issued right after
-      // the step's second MFMA, when the matrix pipe has work queued, instead of all four behind the barrier where it is empty
-      auto dma_here = [&] {
-#if NS_OB16_DMA_SPREAD == 2
-        if constexpr (p % STRIDE == 0 && p / STRIDE < PipeT::LPW) pipe.template issue_piece_saddr<p / STRIDE>();
-#endif
-      };
-#if NS_OB16_PAIR_LOADS
-      // Two fragment reads every other step, the later-consumed one FIRST: the wait for the younger read then covers the
-      // older one too, so a pair costs one s_waitcnt instead of two.  Odd step p refills the slots of chunks p-2 and p-1
-      // (both fully issued) with chunks p+DEPTH-2 and p+DEPTH-1.
-      auto load_next = [&] {
-        dma_here();
-        if constexpr ((p & 1) == 1) {
-          constexpr int DD = PipeT::kDepth;
-          static_assert(DD % 2 == 0 && DD >= 4, "pairing needs an even number of fragment registers");
-          constexpr int qa = p + DD - 1, qb = p + DD - 2;
-          if constexpr (qa < USED) pipe.template load<qa * kChunkBytes>(pipe.f[qa % DD], pipe.cur);
-          else pipe.template load<(qa - USED) * kChunkBytes>(pipe.f[qa % DD], pipe.nxt);
-          if constexpr (qb < USED) pipe.template load<qb * kChunkBytes>(pipe.f[qb % DD], pipe.cur);
-          else pipe.template load<(qb - USED) * kChunkBytes>(pipe.f[qb % DD], pipe.nxt);
-        }
-      };
-#elif NS_OB16_LATE_REFILL
       // refill the slot of the PREVIOUS chunk (its MFMAs were all issued a step ago, so the LDS read does not have to
       // wait out the write-after-read window of an MFMA that is still fetching its A operand): chunk p + DEPTH - 1
       auto load_next = [&] {
-        dma_here();
         constexpr int q = p + PipeT::kDepth - 1;
         if constexpr (q < USED) pipe.template load<q * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.cur);
         else pipe.template load<(q - USED) * kChunkBytes>(pipe.f[q % PipeT::kDepth], pipe.nxt);
       };
-#else
-      auto load_next = [&] {
-        dma_here();
-        if constexpr (p + PipeT::kDepth < USED)
-          pipe.template load<(p + PipeT::kDepth) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.cur);
-        else
-          pipe.template load<(p + PipeT::kDepth - USED) * kChunkBytes>(pipe.f[p % PipeT::kDepth], pipe.nxt);
-      };
-#endif
       op(std::integral_constant<int, s * kSlabChunks + p>{}, pipe.f[p % PipeT::kDepth], load_next);
     });
-#if NS_OB16_DMA_SPREAD == 2
-    static_assert((PipeT::LPW - 1) * STRIDE < USED, "every piece has a chunk step");
-    pipe.issue_advance();
-#elif NS_OB16_DMA_SPREAD
-    static_for<PipeT::LPW>([&](auto i_) {      // pieces a short slab had no chunk step for
-      constexpr int i = decltype(i_)::value;
-      if constexpr (i > 0 && i * STRIDE >= USED) pipe.template issue_piece<i>();
-    });
-    pipe.issue_advance();
-#endif
   });
 }
 // ---- positional-encoding slots -------------------------------------------------------------------
@@ -703,14 +587,8 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 #ifndef NS_OB16_DEPTH
 #define NS_OB16_DEPTH 4
 #endif
-#ifndef NS_OB16_INTERLEAVE
-#define NS_OB16_INTERLEAVE 0   // 1: fence the 16x16x32 chunk step into MFMA / other / MFMA / other (measured: -3 %, not used)
-#endif
 #ifndef NS_OB16_AHEAD
 #define NS_OB16_AHEAD 3
-#endif
-#ifndef NS_OB16_SGB
-#define NS_OB16_SGB 0   // 1: per chunk step, sched_group_barrier pattern MFMA / <=2 VALU / MFMA / DS read + VALU / MFMA / <=2 VALU / MFMA / VALU
 #endif
 constexpr int kOb16Depth = NS_OB16_DEPTH;   // A-fragment read-ahead of the 16x16x32 kernels (one wave per SIMD)
 constexpr int kOb16Ahead = NS_OB16_AHEAD;   // weight slabs in flight ahead of the open one
@@ -808,14 +686,10 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
   constexpr int CONV_END = (PIECES + PPS - 1) / PPS;
   constexpr int BIAS_AT = (NKB - 2) > CONV_END ? (NKB - 2) : (NKB - 1);
   f32x4a c[2][T];
-#if NS_OB16_BIAS_C
-  f32x4a bnext = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);   // bias of the sub-block about to start
-#else
   {
     const f32x4a b0 = *reinterpret_cast<const f32x4a*>(bias_lds + 4 * g);
     static_for<T>([&](auto t_) { c[0][decltype(t_)::value] = b0; });
   }
-#endif
   // A lone wave issues in order: an instruction placed after the MFMA cluster overlaps only the LAST MFMA's
   // execution (16 cycles for this shape), one placed between two MFMAs hides in the wait for the matrix pipe.  So the
   // step is emitted as MFMA / conversion piece / MFMA / fragment read / MFMA / bias / MFMA with scheduling fences.
@@ -826,15 +700,7 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
       const typename M::AFrag frag = frag_ref;
       static_for<T>([&](auto t_) {
         constexpr int t = decltype(t_)::value;
-#if NS_OB16_BIAS_C
-        if constexpr (kc == 0) M::mma_c(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}), bnext);
-        else M::mma(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}));
-#else
         M::mma(c[par][t], frag, in(t_, std::integral_constant<int, kc>{}));
-#endif
-#if NS_OB16_INTERLEAVE
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         if constexpr (t == 0 && sb > 0) {
           static_for<PPS>([&](auto i_) {
             constexpr int piece = kc * PPS + decltype(i_)::value;
@@ -844,32 +710,11 @@ __device__ __forceinline__ void layer_ob16(PipeT& pipe, const float* bias_lds, i
           });
         }
         if constexpr (t == (T > 1 ? 1 : 0)) load_next();
-#if NS_OB16_BIAS_C
-        // the next sub-block's bias is fetched right after this sub-block's first chunk (whose MFMAs read the current
-        // one as their C operand), a whole sub-block ahead of its use: no LDS latency in front of the first MFMA
-        if constexpr (t == T - 1 && kc == (NKB > 1 ? 1 : 0) && sb + 1 < NSB) {
-          static_assert(NKB > 1, "the bias register is read by the first chunk's MFMAs");
-          bnext = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
-        }
-#else
         if constexpr (t == (T > 2 ? 2 : T - 1) && kc == BIAS_AT && sb + 1 < NSB) {
           const f32x4a bn = *reinterpret_cast<const f32x4a*>(bias_lds + 16 * (sb + 1) + 4 * g);
           static_for<T>([&](auto u_) { c[par ^ 1][decltype(u_)::value] = bn; });
         }
-#endif
       });
-#if NS_OB16_SGB
-      // ask the scheduler (IGroupLP) for an even interleave: no more than two VALU fillers between two MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-#endif
     } else {
       load_next();
     }

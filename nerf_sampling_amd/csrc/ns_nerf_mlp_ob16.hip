@@ -60,31 +60,16 @@ using namespace nsmlp;
 #ifndef NS_NERF16_T
 #define NS_NERF16_T 4
 #endif
-#ifndef NS_NERF16_RELOAD_ONCE
-#define NS_NERF16_RELOAD_ONCE 1   // 1: stashed embeddings come back from LDS once per layer, not once per sub-block
-#endif
 #ifndef NS_NERF16_WAVES
 #define NS_NERF16_WAVES 4
 #endif
 #ifndef NS_OB16_PROD_T
 #define NS_OB16_PROD_T 0          // 16-sample tiles per wave in the production kernel: 4, 5, or 0 = chosen per launch
 #endif
-#ifndef NS_OB16_PREFETCH_EARLY
-#define NS_OB16_PREFETCH_EARLY 1  // 1: (all-asm production kernel) the next group's inputs are requested before layer 0 instead of
-                                  // after it: with compiled code between two statements the allocator moved the whole
-                                  // activation set through VGPRs and back (264 copies per group pass; -0.7 % per frame)
-#endif
-#ifndef NS_OB16_ASM_ALL
-#define NS_OB16_ASM_ALL 1         // 1: layer 0, the view layer and the rgb head of the production kernel are generated statements too
-#endif
-#ifndef NS_OB16_ASM
-#define NS_OB16_ASM 1             // 1: the W = 256 hidden layers run the hand-scheduled streams of ns_ob16_asm.inc (tools/gen_ob16_asm.py)
-#endif
 constexpr int kT = NS_NERF16_T;          // 16-sample tiles per wave
 constexpr int kWaves = NS_NERF16_WAVES;  // 4: one wave per SIMD, ~256 AGPRs of activations + accumulators per wave
                                          // (8 waves x T = 2, two per SIMD in 256 registers each: measured slower)
 
-#if NS_OB16_ASM
 }  // namespace
 #ifndef NS_OB16_ASM_INC
 #define NS_OB16_ASM_INC "ns_ob16_asm.inc"
@@ -117,7 +102,7 @@ __device__ __forceinline__ void hidden_layer_asm(PipeT& ring, const float* bias_
     });
   });
 }
-// the other three layers of the production network as generated statements (NS_OB16_ASM_ALL): layer 0, the view layer with
+// the other three layers of the production network as generated statements: layer 0, the view layer with
 // the sigma sub-block, the rgb head
 template <class M, int T, class PipeT>
 __device__ __forceinline__ void layer0_asm(PipeT& ring, const float* bias_lds, int g, const typename M::Block (&xe)[T][2],
@@ -159,7 +144,6 @@ __device__ __forceinline__ void rgb_asm(PipeT& ring, const float* bias_lds, int 
   rgb_asm_run<M, T>(ring, bias_lds, g, A, ACCO);
   static_for<T>([&](auto t_) { last[decltype(t_)::value] = __builtin_bit_cast(f32x4a, ACCO[decltype(t_)::value]); });
 }
-#endif
 
 using nsob16::Nerf16Args;
 
@@ -398,7 +382,6 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     auto in_x = [&](auto t_, auto kb_) -> const Block& { return xe[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_A = [&](auto t_, auto kb_) -> const Block& { return hA[decltype(t_)::value][decltype(kb_)::value]; };
     auto in_B = [&](auto t_, auto kb_) -> const Block& { return hB[decltype(t_)::value][decltype(kb_)::value]; };
-#if NS_NERF16_RELOAD_ONCE
     // The skip layer sees cat[x, h]: the embedded point comes back from the per-wave LDS stash ONCE per layer into
     // registers (32 of them, live for that layer only) instead of once per 16-row sub-block -- 8 reads instead of 128
     // per wave pass, none of them right in front of the MFMA that needs it.
@@ -417,33 +400,17 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       constexpr int kb = decltype(kb_)::value;
       if constexpr (kb < 2) return xs[decltype(t_)::value][kb]; else return hB[decltype(t_)::value][kb - 2];
     };
-#else
-    auto load_xs = [&] {};
-    auto in_xA = [&](auto t_, auto kb_) -> Block {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hA[decltype(t_)::value][kb - 2];
-    };
-    auto in_xB = [&](auto t_, auto kb_) -> Block {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < 2) return stash_get(decltype(t_)::value, kb); else return hB[decltype(t_)::value][kb - 2];
-    };
-#endif
 
     // layer 0: x -> hA
-#if NS_OB16_ASM && NS_OB16_ASM_ALL
     if constexpr (PROD) {
-#if NS_OB16_PREFETCH_EARLY
       prefetch(grp + gridDim.x);
-#endif
       layer0_asm<M, T>(ring, bias, g, xe, hA); bias += NSB * 16;
     } else
-#endif
     { layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16; }
     // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
     // have been consumed (they fed the embeddings above)
-    if constexpr (!(PROD && NS_OB16_ASM && NS_OB16_ASM_ALL && NS_OB16_PREFETCH_EARLY)) prefetch(grp + gridDim.x);
+    if constexpr (!PROD) prefetch(grp + gridDim.x);   // (PROD asked before layer 0: compiled code between two statements costs register copies)
     int l = 1;
-#if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE
     if constexpr (PROD) {
       static_assert(NKB == 8 && (T == 4 || T == 5) && NWAVES == 4, "the generated streams are W = 256, four or five tiles, four waves");
       hidden_layer_asm<M, T, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
@@ -456,7 +423,6 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       hidden_layer_asm<M, T, true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
       l = 8;
     }
-#endif
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     if constexpr (!PROD) {
     for (; l + 1 < a.D; l += 2) {
@@ -493,35 +459,22 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
     // views o feature (folded at pack time: feature_linear has no activation, run_nerf_helpers.py:119-125) on
     // cat[h, dirs27] -> W/2, relu: (hA, ve) -> hB[0 .. NKB/2); alpha_linear rides along as row 0 of one extra, LAST
     // sub-block, whose raw accumulators come back in `last`: sigma = row 0 (lane group 0, register 0)
-#if NS_NERF16_RELOAD_ONCE
     Block vs[T];   // the embedded view direction, once for the layer's 9 sub-blocks
     static_for<T>([&](auto t_) { vs[decltype(t_)::value] = stash_get(decltype(t_)::value, 2); });
     auto in_Av = [&](auto t_, auto kb_) -> const Block& {
       constexpr int kb = decltype(kb_)::value;
       if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
     };
-#else
-    auto in_Av = [&](auto t_, auto kb_) -> Block {
-      constexpr int kb = decltype(kb_)::value;
-      if constexpr (kb < NKB) return hA[decltype(t_)::value][kb]; else return stash_get(decltype(t_)::value, 2);
-    };
-#endif
     float sigma[T];
     if constexpr (PROD) {   // the trunk ended in hB: (hB, ve) -> hA[0 .. NKB/2), then rgb from hA
       auto in_Bv = [&](auto t_, auto kb_) -> const Block& {
         constexpr int kb = decltype(kb_)::value;
         if constexpr (kb < NKB) return hB[decltype(t_)::value][kb]; else return vs[decltype(t_)::value];
       };
-#if NS_OB16_ASM && NS_OB16_ASM_ALL
       (void)in_Bv;
       views_asm<M, T>(ring, bias, g, hB, vs, hA, last); bias += (NSB / 2 + 1) * 16;
       static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
       rgb_asm<M, T>(ring, bias, g, hA, last);
-#else
-      layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hA, last, in_Bv); bias += (NSB / 2 + 1) * 16;
-      static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
-      layer_ob16<M, T, 1, NKB / 2, kNone>(ring, bias, g, hB, last, in_A);
-#endif
     } else {
     layer_ob16<M, T, NSB / 2 + 1, NKB + 1, kRelu>(ring, bias, g, hB, last, in_Av); bias += (NSB / 2 + 1) * 16;
     static_for<T>([&](auto t_) { sigma[decltype(t_)::value] = last[decltype(t_)::value][0]; });
@@ -624,7 +577,7 @@ int launch(Nerf16Args& a, hipStream_t stream) {
 #ifndef NS_OB16_TU_T5
 template <class M, bool EMB>
 int dispatch_m(const ns_weights* net, Nerf16Args& a, hipStream_t stream) {
-#if NS_OB16_ASM && NS_NERF16_RELOAD_ONCE && NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
+#if NS_NERF16_T == 4 && NS_NERF16_WAVES == 4
   if (net->width == 256 && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns::debug_flags().generic_kernels) {
     // the production network: hand-scheduled layers, four or five 16-sample tiles per wave.  Five tiles read 20 % fewer
     // weight fragments and refill bytes per sample (-2.5 % per frame on the final build, profiles/r03c_ab_tiles_final_build.log);

@@ -16,12 +16,8 @@ using namespace nsmlp;
 
 constexpr int kT = 2;        // 16-sample tiles per wave (hi + lo activation blocks: half the tiles of the plain kernel)
 constexpr int kWaves = 4;    // one wave per SIMD: ~256 AGPRs of activations + accumulators per wave
-#ifndef NS_OB16_ASM
-#define NS_OB16_ASM 1        // 1: the production network's hidden layers run the generated streams of ns_ob16_asm.inc
-#endif
 
 
-#if NS_OB16_ASM
 }  // namespace
 #ifndef NS_OB16_ASM_INC
 #define NS_OB16_ASM_INC "ns_ob16_asm.inc"
@@ -56,7 +52,6 @@ __device__ __forceinline__ void hidden_layer_asm_x3(PipeT& ring, const float* bi
     });
   });
 }
-#endif
 
 struct NerfX3Args {
   const char* stream;
@@ -215,7 +210,6 @@ if (a.use_viewdirs) {
     // have been consumed (they fed the embeddings above)
     prefetch(grp + gridDim.x);
     int l = 1;
-#if NS_OB16_ASM
     if constexpr (PROD) {
       static_assert(NKB == 8 && T == 2 && NWAVES == 4, "the generated streams are W = 256, two split tiles, four waves");
       hidden_layer_asm_x3<true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 1
@@ -228,7 +222,6 @@ if (a.use_viewdirs) {
       hidden_layer_asm_x3<true, false>(ring, bias, g, hA, hB, xs); bias += NSB * 16;    // 7: the trunk's output is in hB
       l = 8;
     }
-#endif
     // layers 1 .. D-1, two per trip (hA -> hB -> hA); the layer after `skip` sees cat[x, h]
     if constexpr (!PROD) {
     for (; l + 1 < a.D; l += 2) {
@@ -345,10 +338,8 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
   a.S = S; a.N = N; a.raw = raw_dev;
   const bool emb = x90_dev != nullptr, wide = net->width == 256;
-#if NS_OB16_ASM
   if (wide && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns::debug_flags().generic_kernels)
     return emb ? launch<8, true, true>(a, stream) : launch<8, false, true>(a, stream);   // the production network
-#endif
   if (emb) return wide ? launch<8, true>(a, stream) : launch<4, true>(a, stream);
   return wide ? launch<8, false>(a, stream) : launch<4, false>(a, stream);
 }

@@ -1050,7 +1050,7 @@ struct AsmRingArgs {
 };
 template <class PipeT>
 __device__ __forceinline__ void asm_ring_begin(PipeT& ring, const float* bias_lds, int g, AsmRingArgs& r) {
-  static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16 && NS_OB16_LATE_REFILL,
+  static_assert(PipeT::RING == 4 && PipeT::LPW == 4 && PipeT::kDepth == 4 && kSlabChunks == 16,
                 "the generated streams assume the default ring");
   static_for<4>([&](auto i_) { r.F[decltype(i_)::value] = __builtin_bit_cast(u32x4, ring.f[decltype(i_)::value]); });
   const uint32_t lane16 = ring.lds_off + static_cast<uint32_t>(ring.lane) * 16u;
