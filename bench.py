@@ -503,6 +503,24 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
                     "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
                     "max_abs_err_vs_oracle": float(err.max()), "rays_over_1e-4": float((err > 1e-4).float().mean()),
                     "psnr_vs_oracle_db": psnr(rgb, ref["rgb"][:n]), "oracle_rays": n})
+    # -- the headline shape through the five-launch chain (ns_render_rays_depthnet): the same pixels, the A/B of the one-kernel
+    #    renderer on THIS box, and the MLP kernel timed alone (the one-kernel renderer's launch includes placement + compositing)
+    nw, dw = fine.packed(headline_dtype), dn.packed(ops.depthnet_dtype_for(headline_dtype))
+    events = []
+    t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events, one_kernel=False),
+              events, device)
+    steps = 8
+    elapsed, rgb_chain, _ = t.run(poses, steps, 2, sync)
+    rl = roofline_block(headline_dtype, t.kernel_ms(), H * W, samples, cfg["D"], cfg["W"], cfg["skip"])
+    t1 = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=[]), [], device)
+    _, rgb_one, _ = t1.run(poses, steps, 2, sync)       # the same frames (same poses in the same order) through the one-kernel renderer
+    out.append({"config": f"configs[1] shape ({H}x{W}, DepthNet + {samples} samples), {headline_dtype}, five-launch chain "
+                          "(ns_render_rays_depthnet: placement, MLP and compositing as separate kernels)", "dtype": headline_dtype,
+                "steps": steps, "rays_per_s": H * W * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+                "kernel": "NeRF MLP alone", "kernel_ms": rl["kernel_ms"], "frac": rl["frac"],
+                "executed_mfma_frac": rl["executed_mfma_frac"],
+                "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
+                "pixels_bit_identical_to_the_one_kernel_renderer": bool(torch.equal(rgb_chain, rgb_one))})
     # -- configs[2]: vanilla hierarchical 64 + 128, coarse + fine network, headline dtype; oracle on a thin band
     cw, fw = coarse.packed(headline_dtype), fine.packed(headline_dtype)
     events, cevents = [], []
