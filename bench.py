@@ -529,6 +529,10 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     elapsed, _, _ = t.run(poses, steps, 1, sync)
     cevents = cevents[-len(events):]                 # the warm-up frame's pair was dropped from `events` by Timed.run
     rl = roofline_block(headline_dtype, t.kernel_ms(), H * W, 192, cfg["D"], cfg["W"], cfg["skip"])
+    with ops.debug_switch(hier_chain=1):             # same box, same frames: raw [R,N,4] in HBM + the stand-alone compositing kernel
+        tc = Timed(H, W, hier_rows_fn(ops, cw, fw, H, W, K, device, [], coarse_events=[]), [], device)
+        elapsed_chain, rgb_hc, _ = tc.run(poses, steps, 1, sync)
+    _, rgb_hf, _ = Timed(H, W, hier_rows_fn(ops, cw, fw, H, W, K, device, [], coarse_events=[]), [], device).run(poses, steps, 1, sync)
     coarse_ms = float(np.mean([b.elapsed_ms(e) for b, e in cevents]))
     rlc = roofline_block(headline_dtype, coarse_ms, H * W, 64, cfg["D"], cfg["W"], cfg["skip"])
     b0 = H // 2
@@ -546,6 +550,9 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
                                 "executed_mfma_frac": rlc["executed_mfma_frac"],
                                 "effective_frac_on_reference_flops": rlc["effective_frac_on_reference_flops"]},
                 "ms_outside_the_two_mlp_kernels": 1e3 * elapsed / steps - rl["kernel_ms"] - coarse_ms,
+                "compositing": "in the MLP kernels' epilogues (no raw [R,N,4] array)",
+                "ms_per_step_with_raw_arrays_and_compositing_launches": 1e3 * elapsed_chain / steps,
+                "pixels_bit_identical_to_that_chain": bool(torch.equal(rgb_hc, rgb_hf)),
                 "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
                 "max_abs_err_vs_oracle": float(err.max()), "median_abs_err_vs_oracle": float(err.median()),
                 "psnr_vs_oracle_db": psnr(got, exp), "oracle_rays": int(exp.shape[0])})
@@ -558,6 +565,9 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     steps = 3
     elapsed, _, _ = t.run(poses, steps, 1, sync)
     rl = roofline_block("f16", t.kernel_ms(), H5 * W5, 192, cfg["D"], cfg["W"], cfg["skip"])
+    tc = Timed(H5, W5, hip_row_renderer(dw, nw, H5, W5, K5, 192, "uniform", 0.1, device=device, events=[], one_kernel=False), [], device)
+    elapsed_chain5, rgb5c, _ = tc.run(poses, steps, 1, sync)
+    _, rgb5f, _ = Timed(H5, W5, hip_row_renderer(dw, nw, H5, W5, K5, 192, "uniform", 0.1, device=device, events=[]), [], device).run(poses, steps, 1, sync)
     b0 = H5 // 2
     with torch.no_grad():
         batch, _, _, _ = O.ray_batch_from_camera(H5, W5, K5, poses[pose_k], 2.0, 6.0)
@@ -568,6 +578,9 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     err = (got - exp).abs().max(-1).values
     out.append({"config": f"configs[4] shape ({H5}x{W5}, DepthNet + 192 samples), f16, one GPU", "dtype": "f16",
                 "steps": steps, "rays_per_s": H5 * W5 * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+                "renderer": "one kernel (a ray = three 64-sample chunks on different waves)",
+                "ms_per_step_five_launch_chain": 1e3 * elapsed_chain5 / steps,
+                "pixels_bit_identical_to_the_chain": bool(torch.equal(rgb5c, rgb5f)),
                 "kernel_ms": rl["kernel_ms"], "frac": rl["frac"], "executed_mfma_frac": rl["executed_mfma_frac"],
                 "effective_frac_on_reference_flops": rl["effective_frac_on_reference_flops"],
                 "max_abs_err_vs_oracle": float(err.max()), "median_abs_err_vs_oracle": float(err.median()),

@@ -29,6 +29,7 @@ inline int ew_grid(int64_t n, int block) {
 struct DebugFlags {
   int generic_kernels;   // 1: the production network runs the generic, compiler-scheduled kernels (tests compare the two)
   int prod_tiles;        // 4 / 5: tiles per wave of the 16-bit production kernel; 0 = chosen per launch
+  int hier_chain;        // 1: ns_render_rays_hierarchical keeps raw [R,N,4] in HBM and composites with the stand-alone kernel
 };
 DebugFlags& debug_flags();
 // Per-thread launch hint of the one-call renderers (ns_render.cpp): 4 = this call's per-sample outputs are about to be

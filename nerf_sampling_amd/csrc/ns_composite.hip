@@ -76,8 +76,10 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
     const bool live = r < R;
     float norm = 0.f;
     if (live) norm = nscomp::ray_norm(rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]);
-    nscomp::RayAccum A;
-    for (int base = 0; base < N; base += SW) {
+    // several chunks per ray (only SW == 64 gets here): every chunk's sums are reduced on their own, the chunk totals added
+    // in chunk order (ns_composite_ray.h, add_chunk_totals: the arithmetic the one-kernel renderer reproduces chunk-parallel)
+    nscomp::RayAccum tot;                       // wave-uniform: tot.carry = transmittance entering the next chunk
+    for (int base = 0; SW == 64 && base < N; base += SW) {
       const int i = base + sub;
       const bool ok = live && i < N;
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -90,7 +92,11 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
         if (noise) nz = noise[e];
       }
       float alpha, w;
+      nscomp::RayAccum A;
+      A.carry = tot.carry;
       nscomp::composite_chunk<SW>(A, ok, sub, q, zi, dist_raw, norm, nz, noise != nullptr, alpha, w);
+      tot.carry = A.carry;
+      nscomp::add_chunk_totals(tot, A);
       if (ok) {
         const int64_t e = r * N + i;
         if (alphas_out) alphas_out[e] = alpha;
@@ -98,11 +104,11 @@ raw2outputs_kernel(const float4* __restrict__ raw, const float* __restrict__ z,
       }
     }
     float disp;
-    nscomp::composite_finish<SW>(A, white_bkgd, disp, sub);
+    nscomp::finish_totals(tot, white_bkgd, disp);
     if (live && sub == SW - 1) {
-      if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = A.r; p[1] = A.g; p[2] = A.b; }
-      if (acc_out) acc_out[r] = A.acc;
-      if (depth_out) depth_out[r] = A.depth;
+      if (rgb_out) { float* p = rgb_out + r * rgb_stride; p[0] = tot.r; p[1] = tot.g; p[2] = tot.b; }
+      if (acc_out) acc_out[r] = tot.acc;
+      if (depth_out) depth_out[r] = tot.depth;
       if (disp_out) disp_out[r * disp_stride] = disp;
     }
   }

@@ -48,55 +48,93 @@ __device__ __forceinline__ float seg_scan(float x, float identity, int sub, OP o
   return x;
 }
 
-// One chunk of SW consecutive samples of a ray, one sample per lane (lane `sub` of the SW-lane group).
-//   ok: this lane holds a real sample;  q = raw (rgb, sigma);  zi = its depth;  dist_raw = z[i+1] - z[i] or 1e10 for
-//   the last sample (before the ‖d‖ scaling);  noise = raw_noise_std * randn or 0.
-// Returns alpha and weight of the lane's sample and accumulates the ray sums.
+// One chunk of SW consecutive samples of a ray, one sample per lane (lane `sub` of the SW-lane group), in two stages so that a
+// ray longer than a chunk can have its chunks evaluated side by side (the one-kernel renderer) or one after the other
+// (raw2outputs_kernel) with the same arithmetic:
+//   chunk_local: everything that does not depend on the chunks before -- alpha, the colours, the chunk's OWN inclusive
+//                transmittance product p (lane SW - 1: the chunk's total) and its exclusive form excl;
+//   then, given the transmittance `carry` entering the chunk:  T = carry * excl,  w = alpha * T.
+//   ok: this lane holds a real sample;  q = raw (rgb, sigma);  dist_raw = z[i+1] - z[i] or 1e10 for the last sample (before the
+//   ‖d‖ scaling);  noise = raw_noise_std * randn or 0.
+struct ChunkLocal {
+  float alpha, cr, cg, cb, p, excl;
+};
 template <int SW>
-__device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, float4 q, float zi, float dist_raw,
-                                                float norm, float noise, bool has_noise, float& alpha_out,
-                                                float& w_out) {
-  float alpha = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+__device__ __forceinline__ ChunkLocal chunk_local(bool ok, int sub, float4 q, float dist_raw, float norm, float noise, bool has_noise) {
+  ChunkLocal L;
+  L.alpha = 0.f; L.cr = 0.f; L.cg = 0.f; L.cb = 0.f;
   if (ok) {
     const float dist = dist_raw * norm;
     float sigma = q.w;
     if (has_noise) sigma += noise;
-    alpha = 1.0f - expf(-fmaxf(sigma, 0.0f) * dist);
-    if (sigma != sigma) alpha = sigma;  // relu(NaN) is NaN in torch
-    cr = 1.0f / (1.0f + expf(-q.x));
-    cg = 1.0f / (1.0f + expf(-q.y));
-    cb = 1.0f / (1.0f + expf(-q.z));
+    L.alpha = 1.0f - expf(-fmaxf(sigma, 0.0f) * dist);
+    if (sigma != sigma) L.alpha = sigma;  // relu(NaN) is NaN in torch
+    L.cr = 1.0f / (1.0f + expf(-q.x));
+    L.cg = 1.0f / (1.0f + expf(-q.y));
+    L.cb = 1.0f / (1.0f + expf(-q.z));
   }
-  // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this ray
-  const float p = seg_scan<SW>(ok ? (1.0f - alpha) + 1e-10f : 1.0f, 1.0f, sub, [](float a, float b) { return a * b; });
-  float excl = dpp<kWaveShr1>(1.0f, p);          // the previous lane's inclusive product (lane 0: 1)
-  if (sub == 0) excl = 1.0f;
-  const float T = A.carry * excl;
-  const float w = alpha * T;
-  if constexpr (SW == 64)                        // (shorter segments are whole rays: nothing is carried)
-    A.carry = A.carry * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p), 63));
+  // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this chunk
+  L.p = seg_scan<SW>(ok ? (1.0f - L.alpha) + 1e-10f : 1.0f, 1.0f, sub, [](float a, float b) { return a * b; });
+  L.excl = dpp<kWaveShr1>(1.0f, L.p);          // the previous lane's inclusive product (lane 0: 1)
+  if (sub == 0) L.excl = 1.0f;
+  return L;
+}
+// the chunk's total transmittance factor (SW == 64: lane 63 of the wave), wave-uniform
+__device__ __forceinline__ float chunk_product(const ChunkLocal& L) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, L.p), 63));
+}
+
+// Both stages for a chunk whose entering transmittance is A.carry; accumulates the lane's share of the ray sums into A and
+// returns alpha and weight of the lane's sample.
+template <int SW>
+__device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, float4 q, float zi, float dist_raw,
+                                                float norm, float noise, bool has_noise, float& alpha_out,
+                                                float& w_out) {
+  const ChunkLocal L = chunk_local<SW>(ok, sub, q, dist_raw, norm, noise, has_noise);
+  const float T = A.carry * L.excl;
+  const float w = L.alpha * T;
+  if constexpr (SW == 64) A.carry = A.carry * chunk_product(L);     // (shorter segments are whole rays: nothing is carried)
   if (ok) {
-    A.r += w * cr; A.g += w * cg; A.b += w * cb;
+    A.r += w * L.cr; A.g += w * L.cg; A.b += w * L.cb;
     A.depth += w * zi;
     A.acc += w;
   }
-  alpha_out = alpha;
+  alpha_out = L.alpha;
   w_out = w;
 }
 
-// Reduce the lanes' shares: the LAST lane of each SW-lane group (sub == SW - 1) ends up with the ray's totals in A and its
-// disparity in `disp` (inclusive add-scans on DPP: five independent chains of log2 SW instructions, no LDS traffic).
+// Reduce the lanes' shares: the LAST lane of each SW-lane group (sub == SW - 1) ends up with the group's totals in A
+// (inclusive add-scans on DPP: five independent chains of log2 SW instructions, no LDS traffic).
 template <int SW>
-__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp, int sub) {
+__device__ __forceinline__ void reduce_sums(RayAccum& A, int sub) {
   auto add = [](float a, float b) { return a + b; };
   A.r = seg_scan<SW>(A.r, 0.0f, sub, add);
   A.g = seg_scan<SW>(A.g, 0.0f, sub, add);
   A.b = seg_scan<SW>(A.b, 0.0f, sub, add);
   A.depth = seg_scan<SW>(A.depth, 0.0f, sub, add);
   A.acc = seg_scan<SW>(A.acc, 0.0f, sub, add);
+}
+// disparity and the white background from a ray's totals (sampling_trainer.py:209-220)
+__device__ __forceinline__ void finish_totals(RayAccum& A, int white_bkgd, float& disp) {
   const float q = A.depth / (A.acc + 1e-10f);
   disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));   // torch.max(1e-10, q) propagates NaN
   if (white_bkgd) { A.r += 1.0f - A.acc; A.g += 1.0f - A.acc; A.b += 1.0f - A.acc; }
+}
+// a ray of ONE chunk: the last lane of each SW-lane group ends up with the ray's totals in A and its disparity in `disp`
+template <int SW>
+__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp, int sub) {
+  reduce_sums<SW>(A, sub);
+  finish_totals(A, white_bkgd, disp);
+}
+
+// A ray of SEVERAL 64-sample chunks (N > 64): every chunk's sums are reduced on their own and the chunk totals are added in
+// chunk order -- so the chunks of a ray can be evaluated by different waves (the one-kernel renderer) or one after the other
+// (raw2outputs_kernel) and give the same bits.  `tot` (wave-uniform) += the totals of the chunk whose lane shares are in A.
+__device__ __forceinline__ void add_chunk_totals(RayAccum& tot, RayAccum A) {
+  reduce_sums<64>(A, static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))));
+  auto last = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); };
+  tot.r = tot.r + last(A.r); tot.g = tot.g + last(A.g); tot.b = tot.b + last(A.b);
+  tot.depth = tot.depth + last(A.depth); tot.acc = tot.acc + last(A.acc);
 }
 
 }  // namespace nscomp

@@ -76,6 +76,7 @@ int ns_debug_set(const char* name, int value) {
   if (!name) { ns::set_error("ns_debug_set: null name"); return NS_E_INVALID; }
   ns::DebugFlags& f = ns::debug_flags();
   if (!std::strcmp(name, "generic_kernels")) { f.generic_kernels = value ? 1 : 0; return NS_OK; }
+  if (!std::strcmp(name, "hier_chain")) { f.hier_chain = value ? 1 : 0; return NS_OK; }
   if (!std::strcmp(name, "prod_tiles") && (value == 0 || value == 4 || value == 5)) { f.prod_tiles = value; return NS_OK; }
   ns::set_error("ns_debug_set: unknown switch or value (%s = %d)", name, value);
   return NS_E_INVALID;

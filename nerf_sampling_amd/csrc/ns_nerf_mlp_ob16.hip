@@ -36,7 +36,7 @@ struct Nerf16Args {
   // raw2outputs (sampling_trainer.py:153-230) on the wave scan of ns_composite_ray.h in the epilogue -- raw then never
   // leaves the CU (raw may be NULL).  comp == 1: depths from the array z [S];  comp == 2: sample_points_around_mean
   // ("uniform", utils.py:231-241) evaluated in-kernel from the DepthNet depth mean [R] -- no z array exists.
-  // N must be a power of two <= 64 or a multiple of 64 (whole rays per 64-sample chunk, or whole chunks per ray).
+  // N is a power of two <= 64 (whole rays per 64-sample chunk) or a multiple of 64 up to 512 (whole chunks per ray).
   int comp;
   int n_shift;             // log2 N when N is a power of two, else -1
   const float* mean;
@@ -48,6 +48,10 @@ struct Nerf16Args {
   float* z_out;            // [S] or NULL (comp == 2: the depths the kernel placed)
   float* pts_out;          // [S,3] or NULL
   const float* sig_last;   // NULL, or [R,4]: element 3 of row r replaces sigma of ray r's last sample (the guard pass)
+  // rays longer than a 64-sample chunk (N = 64 m, m = m_chunks >= 2; 0 otherwise): a workgroup then walks sg_groups CONSECUTIVE
+  // groups -- lcm(group samples, N) samples, whole rays -- before it jumps, so that a ray's chunks meet in one workgroup and
+  // the transmittance / sums of the ray that is open at a group boundary carry over in LDS
+  int m_chunks, sg_groups;
 };
 // the five-tile production kernel (PROD, 80 samples per wave): defined in the NS_OB16_TU_T5 unit
 int launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t stream);
@@ -205,6 +209,12 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
   auto csig_at = [&](uint32_t par, int ray) -> CsigPtr {      // ray: index within the group (<= GS / 2 rays)
     return reinterpret_cast<CsigPtr>(static_cast<uintptr_t>(comp_region + GS * 32u + (par * (GS / 2) + static_cast<uint32_t>(ray)) * 4u));
   };
+  // rays of several chunks: per chunk of the group its transmittance factor (cP) and its five sums (cS); the ray that is open
+  // at the group's end: {carry, r, g, b, depth, acc}, two parities (copen[par] is read, copen[par ^ 1] written)
+  auto cscal_at = [&](int k) -> CsigPtr {
+    return reinterpret_cast<CsigPtr>(static_cast<uintptr_t>(comp_region + GS * 36u + static_cast<uint32_t>(k) * 4u));
+  };
+  constexpr int kCP = 0, kCS = 8, kOPEN = 8 + 8 * 8;          // float offsets inside the 128-float scalar block
 
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
@@ -259,10 +269,18 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         static_cast<uintptr_t>(stage_base + slot * kStageRow + (t * 16 + n) * 4));
   };
 
-  prefetch(blockIdx.x);
+  // group order of a workgroup: sg consecutive groups (one, unless rays span several chunks), then a jump of gridDim.x such runs
+  const int sg = a.sg_groups > 1 ? a.sg_groups : 1;
+  auto group_after = [&](int64_t grp_, int gi_) -> int64_t {
+    return gi_ + 1 == sg ? grp_ + static_cast<int64_t>(gridDim.x - 1) * sg + 1 : grp_ + 1;
+  };
+  prefetch(static_cast<int64_t>(blockIdx.x) * sg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   uint32_t par = 0;      // parity of the group pass: which {z, dist} record buffer this group writes (compositing only)
-  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x, par ^= 1u) {
+  int gi = 0;            // position of the group in its run
+  for (int64_t grp = static_cast<int64_t>(blockIdx.x) * sg, nxt_grp = 0; grp < n_groups;
+       grp = nxt_grp, gi = (gi + 1 == sg ? 0 : gi + 1), par ^= 1u) {
+    nxt_grp = group_after(grp, gi);
     Block xe[T][2];   // embedded point (63 -> 64 features); registers for layer 0 only
     // Non-finite inputs: the reference's arithmetic turns a NaN / inf coordinate into NaN in all four outputs (sin / cos,
     // nn.Linear and torch.relu all propagate it).  Here the packed-int16 ReLU would drop the NEGATIVE NaNs the matrix
@@ -322,7 +340,10 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
             const float dist_raw = (j < a.N - 1) ? znext - zz : 1e10f;      // sampling_trainer.py:176-180
             const float d0 = st(3), d1 = st(4), d2 = st(5);
             *czd_at(par, wave * (16 * T) + i) = v2f{zz, dist_raw * nscomp::ray_norm(d0, d1, d2)};
-            if (a.sig_last && j == a.N - 1) *csig_at(par, (wave * (16 * T) + i) >> a.n_shift) = st(10);
+            if (a.sig_last && j == a.N - 1) {      // the guard pass's sigma of this ray's last sample: one slot per ray of the group
+              const int slot = a.m_chunks ? static_cast<int>(sidx / a.N - (grp * GS) / a.N) : ((wave * (16 * T) + i) >> a.n_shift);
+              *csig_at(par, slot) = st(10);
+            }
             if (valid && a.z_out) a.z_out[sidx] = zz;
             if (valid && a.pts_out) {
               float* q = a.pts_out + sidx * 3;
@@ -403,13 +424,13 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
 
     // layer 0: x -> hA
     if constexpr (PROD) {
-      prefetch(grp + gridDim.x);
+      prefetch(nxt_grp);
       layer0_asm<M, T>(ring, bias, g, xe, hA); bias += NSB * 16;
     } else
     { layer_ob16<M, T, NSB, 2, true>(ring, bias, g, hA, last, in_x); convert_last16<M, true, T, NSB>(hA, last); bias += NSB * 16; }
     // next group's inputs (clamped to the last sample past the end: loaded, never used); this group's staged values
     // have been consumed (they fed the embeddings above)
-    if constexpr (!PROD) prefetch(grp + gridDim.x);   // (PROD asked before layer 0: compiled code between two statements costs register copies)
+    if constexpr (!PROD) prefetch(nxt_grp);   // (PROD asked before layer 0: compiled code between two statements costs register copies)
     int l = 1;
     if constexpr (PROD) {
       static_assert(NKB == 8 && (T == 4 || T == 5) && NWAVES == 4, "the generated streams are W = 256, four or five tiles, four waves");
@@ -497,7 +518,103 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
       });
     }
     if constexpr (!EMBEDDED) {
-      if (comp) {
+      if (comp && a.m_chunks) {
+        // Rays of m = N / 64 chunks (N = 128, 192, ...): a ray's chunks sit on different waves, possibly in different groups
+        // of the workgroup's run.  Three phases around two s_barriers, the arithmetic of raw2outputs_kernel's multi-chunk
+        // loop (ns_composite_ray.h: chunk_local, then T = carry * excl with the carry multiplied up chunk by chunk, every
+        // chunk's sums reduced on their own and added in chunk order):
+        //   1  every chunk on its wave: alpha, colours, the chunk's own transmittance scan; its factor P_c -> LDS
+        //   2  carry entering the chunk = (the open ray's carry, if the ray began in an earlier group) x P of the ray's
+        //      earlier chunks of this group, in order; weights; the chunk's five sums -> LDS
+        //   3  lane c of wave 0, for the chunk c that ends a ray or the group: totals in chunk order; a finished ray is written,
+        //      the ray that stays open hands {carry, sums} to the next group
+        const int m = a.m_chunks;
+        const int64_t C0 = grp * T;                      // global index of the group's first chunk
+        constexpr int NCW = (T + NWAVES - 1) / NWAVES;   // chunks a wave may own
+        nscomp::ChunkLocal L[NCW];
+        float zc[NCW];
+        bool okc[NCW];
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave's raw records are in LDS
+        static_for<NCW>([&](auto ci_) {
+          constexpr int ci = decltype(ci_)::value;
+          const int c = wave + NWAVES * ci;
+          if (c < T) {                                   // (wave-uniform)
+            const int i = c * 64 + le;
+            const int64_t s_ = grp * GS + i;
+            okc[ci] = s_ < a.S;
+            const v4f qv = *craw_at(i);
+            const v2f zd = *czd_at(par, i);
+            float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
+            if (a.sig_last) {                            // the guard pass's sigma for the ray's last sample
+              const int64_t sidx = okc[ci] ? s_ : a.S - 1;
+              const int64_t ray = sidx / a.N;
+              if (sidx - ray * a.N == a.N - 1) q.w = *csig_at(par, static_cast<int>(ray - (grp * GS) / a.N));
+            }
+            L[ci] = nscomp::chunk_local<64>(okc[ci], le, q, zd.y, 1.0f, 0.0f, false);
+            zc[ci] = zd.x;
+            if (le == 63) *cscal_at(kCP + c) = L[ci].p;
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_for<NCW>([&](auto ci_) {
+          constexpr int ci = decltype(ci_)::value;
+          const int c = wave + NWAVES * ci;
+          if (c < T) {
+            const int pos = static_cast<int>((C0 + c) % m);          // the chunk's position in its ray
+            const int first = c - pos;                               // the ray's first chunk, as an index of this group
+            float carry = first < 0 ? *cscal_at(kOPEN + 8 * par) : 1.0f;
+            for (int cc = first < 0 ? 0 : first; cc < c; ++cc) carry = carry * *cscal_at(kCP + cc);
+            const float Tr = carry * L[ci].excl;
+            const float w = L[ci].alpha * Tr;
+            const int64_t s_ = grp * GS + c * 64 + le;
+            if (okc[ci] && a.weights) a.weights[s_] = w;
+            nscomp::RayAccum A;
+            if (okc[ci]) {
+              A.r += w * L[ci].cr; A.g += w * L[ci].cg; A.b += w * L[ci].cb;
+              A.depth += w * zc[ci];
+              A.acc += w;
+            }
+            nscomp::reduce_sums<64>(A, le);
+            if (le == 63) {
+              *cscal_at(kCS + 8 * c + 0) = A.r; *cscal_at(kCS + 8 * c + 1) = A.g; *cscal_at(kCS + 8 * c + 2) = A.b;
+              *cscal_at(kCS + 8 * c + 3) = A.depth; *cscal_at(kCS + 8 * c + 4) = A.acc;
+            }
+          }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wave == 0 && le < T) {
+          const int c = le;
+          const int pos = static_cast<int>((C0 + c) % m);
+          const bool ends = pos == m - 1;
+          if (ends || c == T - 1) {
+            const int first = c - pos;
+            nscomp::RayAccum tot;                        // tot.carry: the transmittance behind chunk c
+            if (first < 0) {
+              tot.carry = *cscal_at(kOPEN + 8 * par); tot.r = *cscal_at(kOPEN + 8 * par + 1); tot.g = *cscal_at(kOPEN + 8 * par + 2);
+              tot.b = *cscal_at(kOPEN + 8 * par + 3); tot.depth = *cscal_at(kOPEN + 8 * par + 4); tot.acc = *cscal_at(kOPEN + 8 * par + 5);
+            }
+            for (int cc = first < 0 ? 0 : first; cc <= c; ++cc) {
+              tot.carry = tot.carry * *cscal_at(kCP + cc);
+              tot.r = tot.r + *cscal_at(kCS + 8 * cc); tot.g = tot.g + *cscal_at(kCS + 8 * cc + 1); tot.b = tot.b + *cscal_at(kCS + 8 * cc + 2);
+              tot.depth = tot.depth + *cscal_at(kCS + 8 * cc + 3); tot.acc = tot.acc + *cscal_at(kCS + 8 * cc + 4);
+            }
+            if (ends) {
+              const int64_t r = (C0 + c) / m;
+              if (r * a.N < a.S) {
+                float disp;
+                nscomp::finish_totals(tot, a.white_bkgd, disp);
+                float* prgb = a.rgb + r * a.rgb_stride;
+                prgb[0] = tot.r; prgb[1] = tot.g; prgb[2] = tot.b;
+                a.disp[r * a.disp_stride] = disp;
+              }
+            } else {                                     // the ray goes on in the workgroup's next group
+              const uint32_t np = par ^ 1u;
+              *cscal_at(kOPEN + 8 * np) = tot.carry; *cscal_at(kOPEN + 8 * np + 1) = tot.r; *cscal_at(kOPEN + 8 * np + 2) = tot.g;
+              *cscal_at(kOPEN + 8 * np + 3) = tot.b; *cscal_at(kOPEN + 8 * np + 4) = tot.depth; *cscal_at(kOPEN + 8 * np + 5) = tot.acc;
+            }
+          }
+        }
+      } else if (comp) {
         // raw2outputs in the epilogue (sampling_trainer.py:153-230): the group's samples are T chunks of 64 consecutive
         // samples -- whole rays (N <= 64, a power of two) -- one chunk per wave pass, composited by the lane-level code the
         // stand-alone kernel runs (ns_composite_ray.h: same operations in the same order, so bit-identical to it).
@@ -557,7 +674,7 @@ int launch(Nerf16Args& a, hipStream_t stream) {
   const size_t lds = static_cast<size_t>(Pipe<M, kWaves, 0, kOb16Depth, kOb16Ahead>::kLdsBytes) +
                      ((static_cast<size_t>(a.bias_floats) * 4 + 15) & ~size_t(15)) + static_cast<size_t>(kWaves) * TT * 3 * 1024 +
                      static_cast<size_t>(kWaves) * 11 * (TT * 64) +      // ring | bias | embedding stash | input staging
-                     (a.comp && !EMB ? static_cast<size_t>(kWaves) * TT * 16 * 36 : 0);   // | compositing records (32 B per sample + 8 B per ray pair)
+                     (a.comp && !EMB ? static_cast<size_t>(kWaves) * TT * 16 * 36 + 512 : 0);   // | compositing records (32 B per sample + 8 B per ray pair) + chunk scalars
   if (lds > 160 * 1024) {
     ns::set_error("ns_nerf_forward: %zu bytes of LDS needed (too deep a network for the resident bias image)", lds);
     return NS_E_UNSUPPORTED;
@@ -568,7 +685,15 @@ int launch(Nerf16Args& a, hipStream_t stream) {
   const int64_t n_groups = (n_tiles + kWaves * TT - 1) / (kWaves * TT);
   int cus = ns::cu_count();
   if (cus <= 0) cus = 256;
-  const int grid = static_cast<int>(n_groups < cus ? n_groups : cus);
+  a.sg_groups = 1;
+  if (a.m_chunks) {          // runs of lcm(group samples, N) / group samples consecutive groups: whole rays per run
+    const int gs = kWaves * TT * 16;
+    int x = gs, y = a.N;
+    while (y) { const int t = x % y; x = y; y = t; }
+    a.sg_groups = a.N / x;   // lcm(gs, N) / gs
+  }
+  const int64_t n_runs = (n_groups + a.sg_groups - 1) / a.sg_groups;
+  const int grid = static_cast<int>(n_runs < cus ? n_runs : cus);
   kern<<<grid, kWaves * 64, lds, stream>>>(a);
   NS_LAUNCH_CHECK();
   return NS_OK;
@@ -613,7 +738,8 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
 // which (network, sample count) pairs the kernel composites itself (see Nerf16Args::comp)
 bool ns_nerf_can_composite(const ns_weights* net, int N) {
   return net && net->kind == NS_KIND_NERF && net->layout == 16 && (net->dtype == NS_DTYPE_BF16 || net->dtype == NS_DTYPE_F16) &&
-         net->use_viewdirs && net->out_ch == 4 && N >= 2 && N <= 64 && (N & (N - 1)) == 0;
+         net->use_viewdirs && net->out_ch == 4 &&
+         ((N >= 2 && N <= 64 && (N & (N - 1)) == 0) || (N > 64 && N % 64 == 0 && N <= 512));
 }
 
 // called by ns_nerf_forward / ns_nerf_forward_embedded for handles packed with layout 16 (arguments validated there)
@@ -622,7 +748,8 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
                          float* raw_dev, hipStream_t stream, const ns_composite_args* comp) {
   if (comp) {
     if (!ns_nerf_can_composite(net, N)) {
-      ns::set_error("in-kernel compositing needs a 16-bit NeRF handle with view directions and N a power of two in [2, 64] (N = %d)", N);
+      ns::set_error("in-kernel compositing needs a 16-bit NeRF handle with view directions and N a power of two in [2, 64] or a "
+                    "multiple of 64 up to 512 (N = %d)", N);
       return NS_E_UNSUPPORTED;
     }
     if (pts_dev || x90_dev || !(o_dev && d_dev) || !(z_dev || comp->mean_dev) || !(comp->rgb_dev && comp->disp_dev)) {
@@ -649,6 +776,7 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
     a.mean = comp->mean_dev; a.std_ = comp->std_; a.lin_step = nsplace::linspace_step_of(-comp->std_, comp->std_, N - 1);
     a.n_shift = -1;
     for (int k = 0; k < 31; ++k) if (N == (1 << k)) a.n_shift = k;
+    a.m_chunks = N > 64 ? N / 64 : 0;
     a.white_bkgd = comp->white_bkgd;
     a.rgb = comp->rgb_dev; a.rgb_stride = comp->rgb_stride; a.disp = comp->disp_dev; a.disp_stride = comp->disp_stride;
     a.weights = comp->weights_dev; a.z_out = comp->z_out_dev; a.pts_out = comp->pts_out_dev;

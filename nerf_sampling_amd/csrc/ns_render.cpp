@@ -133,7 +133,7 @@ int ns_render_rays_fused(const ns_render_args* a, void* stream) {
   NS_REQUIRE(a->depthnet && a->nerf, "both networks are required");
   if (!ns_render_fused_supported(a->nerf, a->mode, a->N)) {
     ns::set_error("ns_render_rays_fused: uniform placement, a 16-bit NeRF handle with view directions and n_samples a power "
-                  "of two in [2, 64] are required (mode %d, N %d); use ns_render_rays_depthnet", a->mode, a->N);
+                  "of two in [2, 64] or a multiple of 64 up to 512 are required (mode %d, N %d); use ns_render_rays_depthnet", a->mode, a->N);
     return NS_E_UNSUPPORTED;
   }
   NS_REQUIRE(!a->noise_dev, "uniform placement takes no noise");
@@ -229,12 +229,27 @@ int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   rc = ns_coarse_z_scalar(a->near_, a->far_, R, Nc, a->lindisp, a->t_rand_dev, z_c, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_coarse_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_coarse_begin), ns::as_stream(stream)));
-  rc = ns_nerf_forward(a->coarse, nullptr, o, d, z_c, view, R, Nc, raw_c, stream);
+  // A 16-bit field composites in its own epilogue (Nerf16Args::comp == 1: depths from the z array): raw [R,N,4] -- 16 bytes
+  // per sample written and read back, 2.6 GB per 800 x 800 frame at 64 + 192 samples -- then never exists.  The coarse
+  // pass only yields its weights (its colour goes to a scratch corner of the unused raw_c block).
+  const bool chain = ns::debug_flags().hier_chain != 0;
+  const bool fuse_c = !chain && a->Nf > 0 && ns_nerf_can_composite(a->coarse, Nc);
+  if (fuse_c) {
+    ns_composite_args c{};
+    c.white_bkgd = a->white_bkgd;
+    c.rgb_dev = raw_c; c.rgb_stride = 4; c.disp_dev = raw_c + 3; c.disp_stride = 4;
+    c.weights_dev = w_c;
+    rc = ns_nerf_forward_ob16(a->coarse, nullptr, o, d, z_c, view, nullptr, R * Nc, Nc, nullptr, ns::as_stream(stream), &c);
+  } else {
+    rc = ns_nerf_forward(a->coarse, nullptr, o, d, z_c, view, R, Nc, raw_c, stream);
+  }
   if (rc != NS_OK) return rc;
   if (a->ev_coarse_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_coarse_end), ns::as_stream(stream)));
-  rc = ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, w_c,
-                      stream);
-  if (rc != NS_OK) return rc;
+  if (!fuse_c) {
+    rc = ns_raw2outputs(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, nullptr, nullptr, nullptr, nullptr, nullptr, w_c,
+                        stream);
+    if (rc != NS_OK) return rc;
+  }
   if (a->Nf == 0) {  // no importance samples: the coarse pass is the result
     return ns_raw2outputs_strided(raw_c, z_c, d, nullptr, R, Nc, a->white_bkgd, a->rgb_dev,
                                   a->rgb_stride ? a->rgb_stride : 3, a->disp_dev, a->disp_stride ? a->disp_stride : 1,
@@ -246,7 +261,19 @@ int ns_render_rays_hierarchical(const ns_hier_args* a, void* stream) {
   rc = ns_importance_z(z_c, w_c, R, Nc, a->Nf, a->u_dev, z_f, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_begin) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_begin), ns::as_stream(stream)));
-  rc = ns_nerf_forward(a->fine ? a->fine : a->coarse, nullptr, o, d, z_f, view, R, Nt, raw_f, stream);
+  const ns_weights* fine = a->fine ? a->fine : a->coarse;
+  if (!chain && ns_nerf_can_composite(fine, Nt)) {
+    ns_composite_args c{};
+    c.white_bkgd = a->white_bkgd;
+    c.rgb_dev = a->rgb_dev; c.rgb_stride = a->rgb_stride ? a->rgb_stride : 3;
+    c.disp_dev = a->disp_dev; c.disp_stride = a->disp_stride ? a->disp_stride : 1;
+    c.weights_dev = a->weights_dev;
+    rc = ns_nerf_forward_ob16(fine, nullptr, o, d, z_f, view, nullptr, R * Nt, Nt, a->raw_dev, ns::as_stream(stream), &c);
+    if (rc != NS_OK) return rc;
+    if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
+    return NS_OK;
+  }
+  rc = ns_nerf_forward(fine, nullptr, o, d, z_f, view, R, Nt, raw_f, stream);
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
   return ns_raw2outputs_strided(raw_f, z_f, d, nullptr, R, Nt, a->white_bkgd, a->rgb_dev,

@@ -313,7 +313,9 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     ns_render_rays_fused (placement, MLP and compositing in one persistent kernel: no z / raw array in HBM) -- are
     bit-identical to the operator chain depthnet_forward -> place_samples -> nerf_forward -> raw2outputs, for ragged ray
     counts and several N; the one-kernel path on the production network with four and with five tiles per wave (a ray is one
-    wave's own chunk, or a chunk that straddles two waves) and on the generic kernel."""
+    wave's own chunk, or a chunk that straddles two waves) and on the generic kernel.  N = 128, 192: a ray is several 64-sample
+    chunks on different waves -- and, with 192 samples, in different groups of a workgroup's run (the open ray's transmittance and
+    sums carry over in LDS)."""
     from nerf_sampling_amd import ops
 
     m = gpu_modules(scene)
@@ -323,12 +325,12 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     dn, nf = m["depth"].packed(dtype), m["fine"].packed(dtype)
     o, d, view = ops.get_rays(H, W, K, c2w)[:3]
     mean = ops.depthnet_forward(dn, o, d)
-    for n in (64, 32, 96, 16, 2):
+    for n in (64, 32, 96, 192, 16, 2, 128):
         pts, z = ops.place_samples(o, d, mean, n, "uniform", 0.1)
         raw = ops.nerf_forward_rays(nf, o, d, z, view)
         rgb, disp, acc, depth, alphas, weights = ops.raw2outputs(raw, z, d, None, True)
         variants = [dict(one_kernel=False)]
-        if n != 96:                              # (96 is neither a power of two nor <= 64: only the chain serves it)
+        if n != 96:                              # (96 is neither a power of two <= 64 nor a multiple of 64: only the chain serves it)
             variants += [dict(one_kernel=True, prod_tiles=t, generic_kernels=g) for t, g in ((0, 0), (4, 0), (5, 0), (0, 1))]
         else:
             with pytest.raises(NotImplementedError):
@@ -383,7 +385,7 @@ def test_psnr_guard_replaces_sigma_of_the_last_sample(gpu_modules, dtype):
     dn, nf, gw = m["depth"].packed("f16x3"), m["fine"].packed(dtype), m["fine"].packed("f16x3")
     o, d, view = ops.get_rays(H, W, K, c2w)[:3]
     mean = ops.depthnet_forward(dn, o, d)
-    for n in (64, 32):
+    for n in (64, 32, 192):
         pts, z = ops.place_samples(o, d, mean, n, "uniform", 0.1)
         raw = ops.nerf_forward_rays(nf, o, d, z, view)
         raw_last = ops.nerf_forward_rays(gw, o, d, z[:, -1:].contiguous(), view)
@@ -558,6 +560,42 @@ def test_fused_hierarchical_matches_operator_chain(golden, gpu_modules):
     assert bad <= 0.03
     bad, err = frac_bad(npy(fused["rgb"]), g["perturb_rgb_map"], 2e-4)
     assert bad <= 0.03 and np.median(err) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_hierarchical_in_kernel_compositing_matches_chain(gpu_modules, dtype):
+    """ns_render_rays_hierarchical on 16-bit fields composites both passes in the MLP kernel's epilogue (the coarse pass yields
+    only its weights, the fine pass rgb / disp / weights: no raw [R,N,4] array in HBM).  Bit-identical to the same call with the
+    raw arrays and the stand-alone compositing kernel (debug switch hier_chain), on every kernel variant, for a ragged ray
+    count; 64 + 128 samples (a fine ray is three chunks) and 32 + 32 (one chunk)."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("lego_synth")
+    H, W = 23, 47
+    _, K = O.blender_intrinsics(H, W)
+    c2w = O.pose_spherical(-70.0, -30.0, 4.0)[:3, :4]
+    nc, nf = m["coarse"].packed(dtype), m["fine"].packed(dtype)
+    for n_c, n_i in ((64, 128), (32, 32), (64, 64)):
+        kw = dict(camera=(H, W, K, c2w, 0, H), n_coarse=n_c, n_importance=n_i, lindisp=True, white_bkgd=True)
+        with ops.debug_switch(hier_chain=1):
+            ref = ops.render_rays_hierarchical(nc, nf, extras=True, **kw)
+            torch.cuda.synchronize()
+        for t, g in ((0, 0), (4, 0), (5, 0), (0, 1)):
+            with ops.debug_switch(prod_tiles=t, generic_kernels=g):
+                out = ops.render_rays_hierarchical(nc, nf, extras=True, **kw)
+                lean = ops.render_rays_hierarchical(nc, nf, **kw)
+                torch.cuda.synchronize()
+            if g == 0:
+                for k in ("z", "raw", "weights", "rgb", "disp"):
+                    assert torch.equal(out[k].view(torch.int32), ref[k].view(torch.int32)), (n_c, n_i, t, g, k)
+                assert torch.equal(lean["rgb"].view(torch.int32), ref["rgb"].view(torch.int32)), (n_c, n_i, t)
+                assert torch.equal(lean["disp"].view(torch.int32), ref["disp"].view(torch.int32)), (n_c, n_i, t)
+            else:       # the generic kernel's raw differs from the generated streams' in rounding: compare it with its own chain
+                with ops.debug_switch(hier_chain=1, generic_kernels=1):
+                    refg = ops.render_rays_hierarchical(nc, nf, extras=True, **kw)
+                    torch.cuda.synchronize()
+                for k in ("z", "raw", "weights", "rgb", "disp"):
+                    assert torch.equal(out[k].view(torch.int32), refg[k].view(torch.int32)), (n_c, n_i, "generic", k)
 
 
 def test_full_size_hierarchical_config3(gpu_modules):
