@@ -14,9 +14,11 @@ struct RayAccum {
   float r = 0.f, g = 0.f, b = 0.f, depth = 0.f, acc = 0.f;
 };
 
-// ‖d‖ as torch.norm computes it on the CPU (fma chain)
+// ‖d‖: the sum as torch.norm forms it on the CPU (fma chain), the root on the transcendental unit (v_sqrt_f32, 1 ulp: the
+// correctly rounded sqrtf is that plus two refinement steps and a denormal rescue, 15 instructions per sample for a factor that
+// only scales the exponent of alpha)
 __device__ __forceinline__ float ray_norm(float dx, float dy, float dz) {
-  return sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+  return __builtin_amdgcn_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
 }
 
 // ---- wave-level scans on DPP (gfx9 data-parallel primitives: the shifted operand is read by the VALU instruction itself, no
@@ -48,6 +50,65 @@ __device__ __forceinline__ float seg_scan(float x, float identity, int sub, OP o
   return x;
 }
 
+// The same scan for products over segments of whole rows (SW >= 16) with the shift INSIDE the multiply (v_mul_f32_dpp: a lane
+// whose source lane does not exist is left as it is -- the multiplication by the identity the generic form spends a v_mov and a
+// v_mov_dpp on), one instruction per step.  Each step reads the register the step before wrote: two wait states (s_nop 1) between
+// a VALU write and a DPP read of the same register; s_nop 4 in front covers a VALU write of EXEC by the code before.
+#define NS_DPP_SHR(n) "row_shr:" #n " row_mask:0xf bank_mask:0xf"
+#define NS_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define NS_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+#define NS_MUL_STEP(ctl) "v_mul_f32_dpp %0, %0, %0 " ctl "\n\ts_nop 1\n\t"
+template <int SW>
+__device__ __forceinline__ float seg_scan_mul_rows(float x) {
+  static_assert(SW == 16 || SW == 32 || SW == 64, "whole 16-lane rows");
+  // (ONE asm statement per width: between two statements the compiler may copy the value to another register right in front of
+  // the DPP read, a hazard it does not see inside inline asm)
+  if constexpr (SW == 16)
+    asm volatile("s_nop 4\n\t" NS_MUL_STEP(NS_DPP_SHR(1)) NS_MUL_STEP(NS_DPP_SHR(2)) NS_MUL_STEP(NS_DPP_SHR(4)) NS_MUL_STEP(NS_DPP_SHR(8)) : "+v"(x));
+  else if constexpr (SW == 32)
+    asm volatile("s_nop 4\n\t" NS_MUL_STEP(NS_DPP_SHR(1)) NS_MUL_STEP(NS_DPP_SHR(2)) NS_MUL_STEP(NS_DPP_SHR(4)) NS_MUL_STEP(NS_DPP_SHR(8))
+                 NS_MUL_STEP(NS_DPP_BC15) : "+v"(x));
+  else
+    asm volatile("s_nop 4\n\t" NS_MUL_STEP(NS_DPP_SHR(1)) NS_MUL_STEP(NS_DPP_SHR(2)) NS_MUL_STEP(NS_DPP_SHR(4)) NS_MUL_STEP(NS_DPP_SHR(8))
+                 NS_MUL_STEP(NS_DPP_BC15) NS_MUL_STEP(NS_DPP_BC31) : "+v"(x));
+  return x;
+}
+
+// Five sums at once, reduced INTO THE LAST LANE of every SW-lane segment (the other lanes end up with partial sums that may
+// reach into the segment before: only lane SW - 1 is read).  The operations that reach the last lane are those of seg_scan
+// above in the same order -- the same bits -- as one v_add_f32_dpp per step and sum: the five chains are interleaved, so a
+// register is read four instructions after it was written and no wait states are needed between the steps.
+#define NS_SUM5_STEP(ctl) \
+  "v_add_f32_dpp %0, %0, %0 " ctl "\n\tv_add_f32_dpp %1, %1, %1 " ctl "\n\tv_add_f32_dpp %2, %2, %2 " ctl "\n\t" \
+  "v_add_f32_dpp %3, %3, %3 " ctl "\n\tv_add_f32_dpp %4, %4, %4 " ctl "\n\t"
+#define NS_SUM5_OPS : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)
+template <int SW>
+__device__ __forceinline__ void reduce5(float& a, float& b, float& c, float& d, float& e) {
+  static_assert(SW == 2 || SW == 4 || SW == 8 || SW == 16 || SW == 32 || SW == 64, "a power of two up to the wave");
+  if constexpr (SW == 2) asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_OPS);
+  else if constexpr (SW == 4) asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_STEP(NS_DPP_SHR(2)) NS_SUM5_OPS);
+  else if constexpr (SW == 8) asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_STEP(NS_DPP_SHR(2)) NS_SUM5_STEP(NS_DPP_SHR(4)) NS_SUM5_OPS);
+  else if constexpr (SW == 16)
+    asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_STEP(NS_DPP_SHR(2)) NS_SUM5_STEP(NS_DPP_SHR(4)) NS_SUM5_STEP(NS_DPP_SHR(8)) NS_SUM5_OPS);
+  else if constexpr (SW == 32)
+    asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_STEP(NS_DPP_SHR(2)) NS_SUM5_STEP(NS_DPP_SHR(4)) NS_SUM5_STEP(NS_DPP_SHR(8))
+                 NS_SUM5_STEP(NS_DPP_BC15) NS_SUM5_OPS);
+  else
+    asm volatile("s_nop 4\n\t" NS_SUM5_STEP(NS_DPP_SHR(1)) NS_SUM5_STEP(NS_DPP_SHR(2)) NS_SUM5_STEP(NS_DPP_SHR(4)) NS_SUM5_STEP(NS_DPP_SHR(8))
+                 NS_SUM5_STEP(NS_DPP_BC15) NS_SUM5_STEP(NS_DPP_BC31) NS_SUM5_OPS);
+}
+#undef NS_SUM5_STEP
+#undef NS_SUM5_OPS
+#undef NS_MUL_STEP
+
+// exp and 1 / x on the transcendental unit (v_exp_f32, v_rcp_f32: 1 ulp each) for compositing.  exp(x) = 2^(x log2 e) with the
+// product rounded once: relative error <= (1 + |x| log2 e) 2^-23.  What compositing uses are 1 - exp(-s) and 1 / (1 + exp(-x)),
+// whose ABSOLUTE error that leaves below 7e-8 for every argument (s e^-s <= 0.37; |x| sigma(x) (1 - sigma(x)) <= 0.23) -- the
+// rounding of the fp32 result itself -- at 2 instructions instead of 14 (range-reduced expf) and 1 instead of 10 (IEEE division).
+// +-inf and NaN arguments come out as IEEE says (no inf - inf inside).
+__device__ __forceinline__ float exp_tu(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float rcp_tu(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // One chunk of SW consecutive samples of a ray, one sample per lane (lane `sub` of the SW-lane group), in two stages so that a
 // ray longer than a chunk can have its chunks evaluated side by side (the one-kernel renderer) or one after the other
 // (raw2outputs_kernel) with the same arithmetic:
@@ -67,14 +128,16 @@ __device__ __forceinline__ ChunkLocal chunk_local(bool ok, int sub, float4 q, fl
     const float dist = dist_raw * norm;
     float sigma = q.w;
     if (has_noise) sigma += noise;
-    L.alpha = 1.0f - expf(-fmaxf(sigma, 0.0f) * dist);
+    L.alpha = 1.0f - exp_tu(-fmaxf(sigma, 0.0f) * dist);
     if (sigma != sigma) L.alpha = sigma;  // relu(NaN) is NaN in torch
-    L.cr = 1.0f / (1.0f + expf(-q.x));
-    L.cg = 1.0f / (1.0f + expf(-q.y));
-    L.cb = 1.0f / (1.0f + expf(-q.z));
+    L.cr = rcp_tu(1.0f + exp_tu(-q.x));
+    L.cg = rcp_tu(1.0f + exp_tu(-q.y));
+    L.cb = rcp_tu(1.0f + exp_tu(-q.z));
   }
   // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this chunk
-  L.p = seg_scan<SW>(ok ? (1.0f - L.alpha) + 1e-10f : 1.0f, 1.0f, sub, [](float a, float b) { return a * b; });
+  const float keep = ok ? (1.0f - L.alpha) + 1e-10f : 1.0f;
+  if constexpr (SW >= 16) L.p = seg_scan_mul_rows<SW>(keep);
+  else L.p = seg_scan<SW>(keep, 1.0f, sub, [](float a, float b) { return a * b; });
   L.excl = dpp<kWaveShr1>(1.0f, L.p);          // the previous lane's inclusive product (lane 0: 1)
   if (sub == 0) L.excl = 1.0f;
   return L;
@@ -107,17 +170,13 @@ __device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, f
 // (inclusive add-scans on DPP: five independent chains of log2 SW instructions, no LDS traffic).
 template <int SW>
 __device__ __forceinline__ void reduce_sums(RayAccum& A, int sub) {
-  auto add = [](float a, float b) { return a + b; };
-  A.r = seg_scan<SW>(A.r, 0.0f, sub, add);
-  A.g = seg_scan<SW>(A.g, 0.0f, sub, add);
-  A.b = seg_scan<SW>(A.b, 0.0f, sub, add);
-  A.depth = seg_scan<SW>(A.depth, 0.0f, sub, add);
-  A.acc = seg_scan<SW>(A.acc, 0.0f, sub, add);
+  (void)sub;
+  reduce5<SW>(A.r, A.g, A.b, A.depth, A.acc);
 }
 // disparity and the white background from a ray's totals (sampling_trainer.py:209-220)
 __device__ __forceinline__ void finish_totals(RayAccum& A, int white_bkgd, float& disp) {
-  const float q = A.depth / (A.acc + 1e-10f);
-  disp = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));   // torch.max(1e-10, q) propagates NaN
+  const float q = A.depth * rcp_tu(A.acc + 1e-10f);
+  disp = rcp_tu((q != q) ? q : fmaxf(1e-10f, q));    // torch.max(1e-10, q) propagates NaN
   if (white_bkgd) { A.r += 1.0f - A.acc; A.g += 1.0f - A.acc; A.b += 1.0f - A.acc; }
 }
 // a ray of ONE chunk: the last lane of each SW-lane group ends up with the ray's totals in A and its disparity in `disp`

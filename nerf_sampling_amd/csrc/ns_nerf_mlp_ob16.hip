@@ -316,6 +316,11 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         // them, and the tiles read their depth back from there a few lines down (same wave: LDS order suffices).
         const int lo = opaque_lane();
         constexpr int kPasses = (16 * T + 63) / 64;
+        // group-level scalars: how many of the group's GS samples exist, and the position of its first sample in its ray
+        // (N <= 64 divides the group size: 0;  N = 64 m: the run starts on a ray, every group adds GS mod N)
+        const int64_t left = a.S - grp * GS;
+        const int rem = left < GS ? static_cast<int>(left) : GS;
+        const int jg0 = a.m_chunks ? (gi * GS) % a.N : 0;                 // (wave-uniform 32-bit arithmetic, gi < 8)
 #pragma unroll
         for (int pass = 0; pass < kPasses; ++pass) {
           const int i = pass * 64 + lo;
@@ -324,30 +329,33 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
               return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
                   static_cast<uintptr_t>(stage_base + slot * kStageRow + i * 4));
             };
-            const int64_t s_raw = (grp * NWAVES + wave) * (16 * T) + i;
-            const bool valid = s_raw < a.S;
-            const int64_t sidx = valid ? s_raw : a.S - 1;
-            const int j = a.n_shift >= 0 ? static_cast<int>(static_cast<uint32_t>(sidx) & static_cast<uint32_t>(a.N - 1))
-                                         : static_cast<int>(sidx % a.N);
-            float zz = st(6), znext;
-            if (a.comp == 2) {      // sample_points_around_mean("uniform"): depths j and j + 1 of the ray from its mean
-              const float m = zz;
-              zz = nsplace::uniform_z(m, a.std_, a.lin_step, a.N - 1, j);
-              znext = nsplace::uniform_z(m, a.std_, a.lin_step, a.N - 1, j + 1);
-            } else {
-              znext = st(10);
+            const int ig = wave * (16 * T) + i;                             // the sample's index within the group
+            const bool valid = ig < rem;
+            int j, ray_in_group;                                            // (a sample past the end: any in-range j, never used)
+            if (!a.m_chunks) {                                              // N <= 64, a power of two: whole rays per group
+              j = ig & (a.N - 1); ray_in_group = ig >> a.n_shift;
+            } else {                                                        // N >= 128, jg0 + ig < GS + N <= 3.5 N
+              const int x = jg0 + ig;
+              ray_in_group = (x >= a.N) + (x >= 2 * a.N) + (x >= 3 * a.N);
+              j = x - ray_in_group * a.N;
             }
+            float zz = st(6), znext;
+            if (a.comp == 2)        // sample_points_around_mean("uniform"): depths j and j + 1 of the ray from its mean
+              nsplace::uniform_z_pair(zz, a.std_, a.lin_step, a.N - 1, j, zz, znext);
+            else
+              znext = st(10);
             const float dist_raw = (j < a.N - 1) ? znext - zz : 1e10f;      // sampling_trainer.py:176-180
             const float d0 = st(3), d1 = st(4), d2 = st(5);
-            *czd_at(par, wave * (16 * T) + i) = v2f{zz, dist_raw * nscomp::ray_norm(d0, d1, d2)};
-            if (a.sig_last && j == a.N - 1) {      // the guard pass's sigma of this ray's last sample: one slot per ray of the group
-              const int slot = a.m_chunks ? static_cast<int>(sidx / a.N - (grp * GS) / a.N) : ((wave * (16 * T) + i) >> a.n_shift);
-              *csig_at(par, slot) = st(10);
-            }
-            if (valid && a.z_out) a.z_out[sidx] = zz;
-            if (valid && a.pts_out) {
-              float* q = a.pts_out + sidx * 3;
-              q[0] = st(0) + d0 * zz; q[1] = st(1) + d1 * zz; q[2] = st(2) + d2 * zz;
+            *czd_at(par, ig) = v2f{zz, dist_raw * nscomp::ray_norm(d0, d1, d2)};
+            // the guard pass's sigma of this ray's last sample: one slot per ray of the group
+            if (a.sig_last && j == a.N - 1) *csig_at(par, ray_in_group) = st(10);
+            if (valid && (a.z_out || a.pts_out)) {
+              const int64_t sidx = grp * GS + ig;
+              if (a.z_out) a.z_out[sidx] = zz;
+              if (a.pts_out) {
+                float* q = a.pts_out + sidx * 3;
+                q[0] = st(0) + d0 * zz; q[1] = st(1) + d1 * zz; q[2] = st(2) + d2 * zz;
+              }
             }
           }
         }
@@ -546,9 +554,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
             const v2f zd = *czd_at(par, i);
             float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
             if (a.sig_last) {                            // the guard pass's sigma for the ray's last sample
-              const int64_t sidx = okc[ci] ? s_ : a.S - 1;
-              const int64_t ray = sidx / a.N;
-              if (sidx - ray * a.N == a.N - 1) q.w = *csig_at(par, static_cast<int>(ray - (grp * GS) / a.N));
+              const int x = (gi * GS) % a.N + i;         // position counted from the start of the group's first ray
+              const int k = (x >= a.N) + (x >= 2 * a.N) + (x >= 3 * a.N);
+              if (x - k * a.N == a.N - 1) q.w = *csig_at(par, k);
             }
             L[ci] = nscomp::chunk_local<64>(okc[ci], le, q, zd.y, 1.0f, 0.0f, false);
             zc[ci] = zd.x;

@@ -41,4 +41,23 @@ __device__ __forceinline__ float uniform_z(float m, float std_, float step, int 
   return (m != m) ? m : v;
 }
 
+// z[j] and z[j + 1] of the same ray at once (the one-kernel renderer needs a sample's depth and the distance to the next one):
+// the three grid values a_{j-1}, a_j, a_{j+1} are evaluated once, the selections are those of uniform_z -- the same bits.
+__device__ __forceinline__ void uniform_z_pair(float m, float std_, float step, int steps, int j, float& z, float& z_next) {
+  const int half = steps / 2;
+  auto grid = [&](int k) {             // m + linspace_step(-std, std, step, steps, k)
+    return m + ((k < half || steps <= 1) ? -std_ + step * static_cast<float>(k) : std_ - step * static_cast<float>(steps - k - 1));
+  };
+  const float am = grid(j - 1), a0 = grid(j), ap = grid(j + 1);       // (out-of-range k: evaluated, never selected)
+  auto pick = [&](int jj, float below, float here) {                   // uniform_z(jj) from a_{jj-1} = below, a_jj = here
+    float v = m;
+    if (jj < steps && here < m) v = here;
+    if (v == m && jj >= 1 && !(below < m)) v = below;
+    v = fminf(fmaxf(v, 2.0f), 6.0f);
+    return (m != m) ? m : v;
+  };
+  z = pick(j, am, a0);
+  z_next = pick(j + 1, a0, ap);
+}
+
 }  // namespace nsplace
