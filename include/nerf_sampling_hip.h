@@ -93,7 +93,9 @@ int ns_pack_nerf(int D, int W, int skip, const float* const* w, const float* con
  * ns_pack_nerf (w/b: D + 4 tensors; raw has 4 channels whatever output_ch says, :126-131).  use_viewdirs == 0: the
  * head is output_linear (W -> output_ch, :132-133; w/b: D + 1 tensors, pts_linears.0..D-1 then output_linear), the
  * network takes no view directions, and raw has output_ch channels (create_nerf builds 5 with N_importance > 0,
- * nerf_utils.py:405-406).                                                                                        */
+ * nerf_utils.py:405-406).  W: any width from 2 to 256 (netwidth, nerf_utils.py:409-423): the kernels are instantiated
+ * for 128 and 256 and the packer zero-pads every tensor to the next of the two -- a padded unit is relu(0) = 0 and feeds
+ * zero columns, so the real units sum the same products plus exact zeros.                                           */
 int ns_pack_nerf_ex(int D, int W, uint32_t skip_mask, int use_viewdirs, int output_ch,
                     const float* const* w, const float* const* b, int dtype, ns_weights** out);
 /* channels of the raw output of a packed NeRF (4, or output_ch without view directions) */

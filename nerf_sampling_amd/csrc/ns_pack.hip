@@ -322,10 +322,47 @@ int ns_pack_nerf_ex(int D, int W, uint32_t skip_mask, int use_viewdirs, int outp
   NS_REQUIRE(out && w && b, "null pointer");
   *out = nullptr;
   const int out_ch = use_viewdirs ? 4 : output_ch;
+  if (W >= 1 && W <= 256 && W != 128 && W != 256 && D >= 1 && D <= 32) {
+    // Any width up to 256 runs on the W = 128 / 256 kernels: every tensor is zero-padded to the next kernel width Wp.  A padded
+    // hidden unit has zero weights and a zero bias -- relu(0) = 0 -- and feeds zero columns of the next layer, so every real
+    // unit sums the same products plus exact zeros: the same network (run_nerf_helpers.py:87-105 with W -> Wp).
+    const int Wp = W <= 128 ? 128 : 256, HV = W / 2, HVp = Wp / 2;
+    auto skipped = [skip_mask](int l) { return l >= 1 && ((skip_mask >> (l - 1)) & 1u) != 0; };
+    const int n_tensors = use_viewdirs ? D + 4 : D + 1;
+    for (int i = 0; i < n_tensors; ++i) NS_REQUIRE(w[i] && b[i], "null weight tensor");
+    std::vector<std::vector<float>> pw(n_tensors), pb(n_tensors);
+    // rows x cols -> prows x pcols; source column k lands in column k (k < split) or k - split + psplit (the columns behind a
+    // block of hidden features that grew from `split` to `psplit`)
+    auto pad = [&](int i, int rows, int cols, int prows, int pcols, int split, int psplit) {
+      pw[i].assign(static_cast<size_t>(prows) * pcols, 0.0f);
+      pb[i].assign(prows, 0.0f);
+      for (int r = 0; r < rows; ++r) {
+        for (int k = 0; k < cols; ++k)
+          pw[i][static_cast<size_t>(r) * pcols + (k < split ? k : k - split + psplit)] = w[i][static_cast<size_t>(r) * cols + k];
+        pb[i][r] = b[i][r];
+      }
+    };
+    pad(0, W, 63, Wp, 63, 63, 63);
+    for (int l = 1; l < D; ++l) {
+      if (skipped(l)) pad(l, W, 63 + W, Wp, 63 + Wp, 63 + W, 63 + Wp);     // cat[x(63), h(W)]: the hidden block is last
+      else pad(l, W, W, Wp, Wp, W, Wp);
+    }
+    if (use_viewdirs) {
+      pad(D, W, W, Wp, Wp, W, Wp);                       // feature_linear
+      pad(D + 1, 1, W, 1, Wp, W, Wp);                    // alpha_linear
+      pad(D + 2, HV, W + 27, HVp, Wp + 27, W, Wp);       // views_linears.0 on cat[feature(W), dirs(27)]
+      pad(D + 3, 3, HV, 3, HVp, HV, HVp);                // rgb_linear
+    } else {
+      pad(D, out_ch, W, out_ch, Wp, W, Wp);              // output_linear
+    }
+    std::vector<const float*> wp(n_tensors), bp(n_tensors);
+    for (int i = 0; i < n_tensors; ++i) { wp[i] = pw[i].data(); bp[i] = pb[i].data(); }
+    return ns_pack_nerf_ex(D, Wp, skip_mask, use_viewdirs, output_ch, wp.data(), bp.data(), dtype, out);
+  }
   if (!(W == 128 || W == 256) || D < 1 || D > 32 || (skip_mask >> (D - 1)) != 0 || out_ch < 1 || out_ch > 16 ||
       !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
     ns::set_error("ns_pack_nerf: unsupported network (W=%d D=%d skips=0x%x output_ch=%d dtype=%d); kernels exist for "
-                  "W in {128,256}, D <= 32, skips before the last layer, input_ch 63 (/27), output_ch <= 16", W, D, skip_mask,
+                  "W <= 256, D <= 32, skips before the last layer, input_ch 63 (/27), output_ch <= 16", W, D, skip_mask,
                   out_ch, dtype);
     return NS_E_UNSUPPORTED;
   }

@@ -6,7 +6,7 @@
 struct ns_weights {
   int kind;       // 0 = NeRF, 1 = DepthNet
   int dtype;      // NS_DTYPE_*
-  int width;      // hidden width W (128 or 256); DepthNet: the width every trunk layer is zero-padded to
+  int width;      // hidden width the kernels run (128 or 256): every layer is zero-padded to it at pack time
   int depth;      // NeRF: D;  DepthNet: number of trunk layers (the skip branches are folded into trunk layer 0)
   int skip;       // NeRF: first skip index or -1 (legacy view of skip_mask)
   uint32_t skip_mask;   // NeRF: bit i set <=> i in skips, i.e. layer i + 1 sees cat[x, h] (run_nerf_helpers.py:117-118)

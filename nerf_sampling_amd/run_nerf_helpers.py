@@ -81,12 +81,13 @@ class NeRF(nn.Module):
 
     # -- packing ---------------------------------------------------------------------------------
     def _check_supported(self):
-        """The HIP kernels cover the reference's whole constructor (run_nerf_helpers.py:67-105) for W in {128, 256}: any
-        D <= 32, any ``skips`` list, both heads (use_viewdirs True / False with output_linear).  Returns the active skips."""
+        """The HIP kernels cover the reference's whole constructor (run_nerf_helpers.py:67-105) for W <= 256 (the packer
+        zero-pads a width to the next kernel width, 128 or 256: the same arithmetic plus exact zeros): any D <= 32, any
+        ``skips`` list, both heads (use_viewdirs True / False with output_linear).  Returns the active skips."""
         if self.input_ch != 63 or (self.use_viewdirs and self.input_ch_views != 27):
             raise NotImplementedError("the HIP kernel is built for multires=10 / multires_views=4 (63+27 inputs)")
-        if self.W not in (128, 256):
-            raise NotImplementedError(f"the HIP kernels are built for W in (128, 256), got {self.W}")
+        if not 2 <= self.W <= 256:
+            raise NotImplementedError(f"the HIP kernels are built for 2 <= W <= 256, got {self.W}")
         return sorted({int(s_) for s_ in self.skips if 0 <= int(s_) < self.D - 1})
 
     @property

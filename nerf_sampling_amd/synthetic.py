@@ -186,6 +186,16 @@ NERF_VARIANTS = {
                             hidden_gain=SQRT6, spectral_decay=True),
 }
 
+# NeRF widths other than the two the kernels are instantiated for (netwidth / netwidth_fine of the reference's configs,
+# nerf_utils.py:409-423): the packer zero-pads them to 128 / 256.  Pinned against the reference by tests/golden/nerf_widths.npz.
+NERF_WIDTHS = {
+    "w64": dict(seed=91, D=4, W=64, skips=(1,), use_viewdirs=True, hidden_gain=SQRT6, spectral_decay=True),
+    "w200": dict(seed=92, D=8, W=200, skips=(4,), use_viewdirs=True, hidden_gain=SQRT6, spectral_decay=True),
+    "w97_odd": dict(seed=93, D=3, W=97, skips=(), use_viewdirs=True, hidden_gain=SQRT6, spectral_decay=True),
+    "w40_no_viewdirs": dict(seed=94, D=4, W=40, skips=(2,), use_viewdirs=False, output_ch=5, input_ch_views=0,
+                            hidden_gain=SQRT6, spectral_decay=True),
+}
+
 # DepthNet shapes other than one uniform width, pinned against the reference by tests/golden/depthnet_shapes.npz:
 # tag -> (hidden_sizes, cat_hidden_sizes, seed).  "default" is the reference's class default (depth_net.py:13-16).
 DEPTHNET_SHAPES = {

@@ -449,6 +449,41 @@ def test_nerf_constructor_variants(ops, golden, tag, dtype, tol):
         assert np.abs(fwd.cpu().numpy().reshape(exp.shape) - exp).max() / scale.max() < 2e-5
 
 
+@pytest.mark.parametrize("tag", ["w64", "w200", "w97_odd", "w40_no_viewdirs"])
+@pytest.mark.parametrize("dtype,tol", [("f32", 7e-6), ("f16x3", 7e-6), ("f16", 6.5e-3), ("bf16", 5.2e-2)])   # the gates of the constructor variants
+def test_nerf_widths_other_than_the_kernel_widths(ops, golden, tag, dtype, tol):
+    """netwidth / netwidth_fine other than 128 / 256 (nerf_utils.py:409-423; run_nerf_helpers.py:87-105 builds W // 2 view
+    channels, so an odd width is legal): ns_pack_nerf_ex zero-pads every tensor to the next kernel width -- a padded unit is
+    relu(0) = 0 feeding zero columns, the real units sum the same products plus exact zeros.  Expected raw from the reference's
+    own module; the packed handle reports the kernel width it runs on."""
+    from nerf_sampling_amd import synthetic
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+    g = golden("nerf_widths")
+    kw = synthetic.NERF_WIDTHS[tag]
+    net = NeRF(D=kw["D"], W=kw["W"], input_ch=63, input_ch_views=kw.get("input_ch_views", 27), output_ch=kw.get("output_ch", 4),
+               skips=list(kw["skips"]), use_viewdirs=kw["use_viewdirs"])
+    net.load_state_dict(synthetic.make_nerf_params(**kw))
+    net = net.cuda()
+    exp = g[f"raw_{tag}"]
+    view = dev(g["viewdirs"]) if kw["use_viewdirs"] else None
+    raw = ops.nerf_forward(net.packed(dtype), dev(g["pts"]), view)
+    assert tuple(raw.shape) == exp.shape
+    scale = np.abs(exp).reshape(-1, exp.shape[-1]).max(0)
+    err = np.abs(raw.cpu().numpy() - exp) / scale
+    print(f"nerf width {tag} [{dtype}]: max err / channel scale {err.max():.2e}")
+    assert err.max() < tol, (tag, dtype, float(err.max()))
+
+
+def test_nerf_width_beyond_the_kernels_is_refused(ops):
+    from nerf_sampling_amd import synthetic
+    from nerf_sampling_amd.run_nerf_helpers import NeRF
+
+    net = NeRF(D=2, W=320, input_ch=63, input_ch_views=27, output_ch=4, skips=[], use_viewdirs=True).cuda()
+    with pytest.raises(NotImplementedError):
+        net.packed("f32")
+
+
 @pytest.mark.parametrize("scene", ["tiny_synth", "lego_synth"])
 def test_nerf_forward_embedded_and_rays(ops, gpu_modules, golden, scene):
     g = golden("nerf_mlp")

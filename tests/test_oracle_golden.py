@@ -356,3 +356,17 @@ def test_nerf_variants(golden, tag):
     raw = O.run_network(p, T(g["pts"]), view, skips=kw["skips"])
     assert raw.shape == g[f"raw_{tag}"].shape
     close(raw, g[f"raw_{tag}"], 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("tag", ["w64", "w200", "w97_odd", "w40_no_viewdirs"])
+def test_nerf_widths(golden, tag):
+    """netwidth other than 128 / 256 (nerf_utils.py:409-423), an odd width included: W // 2 channels in the view branch."""
+    from nerf_sampling_amd import synthetic
+
+    g = golden("nerf_widths")
+    kw = synthetic.NERF_WIDTHS[tag]
+    p = synthetic.make_nerf_params(**kw)
+    view = T(g["viewdirs"]) if kw["use_viewdirs"] else None
+    raw = O.run_network(p, T(g["pts"]), view, skips=kw["skips"])
+    assert raw.shape == g[f"raw_{tag}"].shape
+    close(raw, g[f"raw_{tag}"], 1e-5, 1e-5)

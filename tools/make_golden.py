@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from oracle import nerf_oracle as O  # noqa: E402  (weight generators + camera only)
 from ref_import import import_reference  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("NS_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
 
 
@@ -415,6 +415,22 @@ def main():
             else:
                 out[f"raw_{tag}"] = tr.run_network(pts_v, None, net, embed_fn=embed_fn, embeddirs_fn=None)
         save("nerf_variants", **out)
+
+        # ---- a7 widths other than 128 / 256 (netwidth, nerf_utils.py:409-423), an odd one included (W // 2 channels in the view
+        #      branch, run_nerf_helpers.py:94-103): the same points through the reference's module
+        print("a7 nerf widths")
+        out = {"pts": pts_v, "viewdirs": view_v}
+        for tag, kw in synthetic.NERF_WIDTHS.items():
+            params = synthetic.make_nerf_params(**kw)
+            net = ref.helpers.NeRF(D=kw["D"], W=kw["W"], input_ch=63, input_ch_views=kw.get("input_ch_views", 27),
+                                   output_ch=kw.get("output_ch", 4), skips=list(kw["skips"]), use_viewdirs=kw["use_viewdirs"])
+            net.load_state_dict(params)
+            net.eval()
+            if kw["use_viewdirs"]:
+                out[f"raw_{tag}"] = tr.run_network(pts_v, view_v, net, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn)
+            else:
+                out[f"raw_{tag}"] = tr.run_network(pts_v, None, net, embed_fn=embed_fn, embeddirs_fn=None)
+        save("nerf_widths", **out)
 
     if "--stats" in sys.argv:
         w = out  # noqa
