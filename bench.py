@@ -469,19 +469,23 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     from nerf_sampling_amd import analytic_scene
     gt_band = analytic_scene.frame(H, W, K, poses[pose_k], r0, r1)[0].reshape(-1, 3)
     # (label, field operands, guarded, timed steps); "guarded" = ops.set_psnr_guard: f16x3 DepthNet + every ray's last sample on f16x3
-    for label, dtype, guarded, steps in ((f"{headline_dtype} + PSNR guard", headline_dtype, True, 5), ("f16x3", "f16x3", False, 4),
-                                         ("f32", "f32", False, 3),
-                                         ("f16" if headline_dtype == "bf16" else "bf16",) * 2 + (False, 5)):
+    # "guarded": None, or the guard threshold -- 16 (the default): only rays whose own sigma_last is within 16 of zero are
+    # re-evaluated, after the kernel; 0: every ray, before the kernel
+    for label, dtype, guarded, steps in ((f"{headline_dtype} + PSNR guard", headline_dtype, 16.0, 5),
+                                         (f"{headline_dtype} + PSNR guard on every ray", headline_dtype, 0.0, 4),
+                                         ("f16x3", "f16x3", None, 4), ("f32", "f32", None, 3),
+                                         ("f16" if headline_dtype == "bf16" else "bf16",) * 2 + (None, 5)):
+        thr, guarded = guarded, guarded is not None
         nw = fine.packed(dtype)
         dw = dn.packed("f16x3" if guarded else ops.depthnet_dtype_for(dtype))
         gw = fine.packed("f16x3") if guarded else None
         events = []
-        t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events, guard=gw),
-                  events, device)
+        t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events, guard=gw,
+                                         guard_threshold=thr), events, device)
         elapsed, _, _ = t.run(poses, steps, 1, sync)
         rl = roofline_block(dtype, t.kernel_ms(), H * W, samples, cfg["D"], cfg["W"], cfg["skip"])
         rgb = ops.render_rays_depthnet(dw, nw, camera=(H, W, K, poses[pose_k], r0, r1), n_samples=samples, mode="uniform",
-                                       std=0.1, device=device, guard=gw)["rgb"].cpu()
+                                       std=0.1, device=device, guard=gw, guard_threshold=thr)["rgb"].cpu()
         err = (rgb - ref["rgb"][:n]).abs().max(-1).values
         mse_err = float(((rgb - ref["rgb"][:n]) ** 2).mean())
         p_ref, p_build = psnr(ref["rgb"][:n], gt_band), psnr(rgb, gt_band)
@@ -491,7 +495,7 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
         last_rms = float((raw_hip[:, -1, 3] - raw_o[:, -1, 3]).pow(2).mean().sqrt())
         ill = step_rule_mask(O, raw_o, z_o, d_o, ref["rgb"][:n], 3.0 * last_rms)
         out.append({"config": f"configs[1] shape ({H}x{W}, DepthNet + {samples} samples), {label}", "dtype": dtype,
-                    "depthnet_operands": dw.dtype, "psnr_guard": guarded,
+                    "depthnet_operands": dw.dtype, "psnr_guard": guarded, "guard_threshold": thr,
                     "scene_psnr": {"oracle_fp32_db": p_ref, "build_db": p_build, "delta_db": p_build - p_ref,
                                    "within_0.05_db": abs(p_build - p_ref) <= 0.05},
                     "breakeven_scene_psnr_db": (-10.0 * float(np.log10(mse_err / 0.011579))) if mse_err > 0 else None,

@@ -232,6 +232,13 @@ typedef struct ns_render_args {
    * last sample of every ray is evaluated a second time through it (R of the R*N samples, ~5 % of the frame) and its
    * sigma replaces the 16-bit one before compositing.  Pair it with an F16X3 DepthNet handle for fp32-grade depths.  */
   const ns_weights* nerf_guard;
+  /* 0: the guard re-evaluates the last sample of EVERY ray.  > 0 (ns_render_rays_fused, N <= 64): only of the rays whose own
+   * 16-bit sigma of that sample lies within this distance of zero -- the only ones whose step can flip: a sigma beyond it
+   * composites to alpha = 0 or 1 either way -- found by the kernel itself, re-evaluated afterwards on a compacted list
+   * (three small launches; the count never leaves the device) and their pixels re-added from the kernel's partial sums, bit
+   * for bit what the every-ray guard gives wherever |sigma16 - sigma32| < guard_threshold.  The five-launch chain
+   * (ns_render_rays_depthnet) ignores it and guards every ray.                                                            */
+  float guard_threshold;
 } ns_render_args;
 int64_t ns_render_workspace_bytes(int64_t R, int N);
 int ns_render_rays_depthnet(const ns_render_args* args, void* stream);

@@ -38,7 +38,7 @@ class RenderArgs(C.Structure):
         ("rgb_dev", _p), ("disp_dev", _p), ("z_dev", _p), ("weights_dev", _p), ("pts_dev", _p),
         ("ev_mlp_begin", _p), ("ev_mlp_end", _p),
         ("rgb_stride", _i64), ("disp_stride", _i64),
-        ("nerf_guard", _p),
+        ("nerf_guard", _p), ("guard_threshold", _f),
     ]
 
 

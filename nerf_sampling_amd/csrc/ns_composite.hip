@@ -482,6 +482,71 @@ patch_sigma_last_kernel(float4* __restrict__ raw, const float4* __restrict__ raw
 }
 }  // namespace
 // sigma of every ray's last sample <- the guard pass's (ns_render_args::nerf_guard; the chain renderer)
+// ---- the selective guard (ns_render_args::guard_threshold): the one-kernel renderer left a record per ray whose 16-bit sigma of
+// the last sample lies within the threshold of zero (Nerf16Args::fix_rec); the count lives on the device, the launches cover the
+// capacity and return at once past it.
+__device__ __forceinline__ int64_t fix_ray_of(const float* rec) {
+  return static_cast<int64_t>(static_cast<uint64_t>(__builtin_bit_cast(uint32_t, rec[11])) |
+                              (static_cast<uint64_t>(__builtin_bit_cast(uint32_t, rec[12])) << 32));
+}
+// inputs of the flagged rays' last samples, compacted for the fp32-grade network (N = 1 "rays")
+__global__ void __launch_bounds__(256)
+fix_gather_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ count, int64_t cap, const float* __restrict__ o,
+                  const float* __restrict__ d, const float* __restrict__ view, float* __restrict__ o_c, float* __restrict__ d_c,
+                  float* __restrict__ view_c, float* __restrict__ z_c) {
+  int64_t n = static_cast<int64_t>(*count);
+  if (n > cap) n = cap;
+  for (int64_t s = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x; s < n; s += static_cast<int64_t>(gridDim.x) * 256) {
+    const float* q = rec + s * 16;
+    const int64_t r = fix_ray_of(q);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o_c[s * 3 + c] = o[r * 3 + c]; d_c[s * 3 + c] = d[r * 3 + c]; view_c[s * 3 + c] = view[r * 3 + c]; }
+    z_c[s] = q[9];
+  }
+}
+// the flagged pixels again: tree sums + the last sample's share with the re-evaluated sigma (nscomp::recomposite_last: the very
+// additions composite_finish makes, so a ray whose sigma keeps its sign comes out bit-identical to the every-ray guard)
+__global__ void __launch_bounds__(256)
+fix_last_sample_kernel(const float* __restrict__ rec, const uint32_t* __restrict__ count, int64_t cap, const float4* __restrict__ raw_c,
+                       int N, int white_bkgd, float* __restrict__ rgb, int64_t rgb_stride, float* __restrict__ disp_out,
+                       int64_t disp_stride, float* __restrict__ weights) {
+  int64_t n = static_cast<int64_t>(*count);
+  if (n > cap) n = cap;
+  for (int64_t s = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x; s < n; s += static_cast<int64_t>(gridDim.x) * 256) {
+    const float* q = rec + s * 16;
+    const int64_t r = fix_ray_of(q);
+    nscomp::RayAccum A;
+    A.r = q[0]; A.g = q[1]; A.b = q[2]; A.depth = q[3]; A.acc = q[4];
+    float disp, w;
+    nscomp::recomposite_last(A, q[5], q[6], q[7], q[8], raw_c[s].w, q[9], q[10], white_bkgd, disp, w);
+    float* p = rgb + r * rgb_stride;
+    p[0] = A.r; p[1] = A.g; p[2] = A.b;
+    disp_out[r * disp_stride] = disp;
+    if (weights) weights[r * N + (N - 1)] = w;
+  }
+}
+
+int ns_fix_gather(const float* rec_dev, const uint32_t* count_dev, int64_t cap, const float* o_dev, const float* d_dev,
+                  const float* view_dev, float* o_c, float* d_c, float* view_c, float* z_c, void* stream) {
+  NS_REQUIRE(rec_dev && count_dev && cap >= 0 && o_dev && d_dev && view_dev && o_c && d_c && view_c && z_c, "bad arguments");
+  if (cap == 0) return NS_OK;
+  fix_gather_kernel<<<ns::ew_grid(cap, 256), 256, 0, ns::as_stream(stream)>>>(rec_dev, count_dev, cap, o_dev, d_dev, view_dev, o_c,
+                                                                             d_c, view_c, z_c);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
+int ns_fix_last_sample(const float* rec_dev, const uint32_t* count_dev, int64_t cap, const float* raw_c, int N, int white_bkgd,
+                       float* rgb_dev, int64_t rgb_stride, float* disp_dev, int64_t disp_stride, float* weights_dev, void* stream) {
+  NS_REQUIRE(rec_dev && count_dev && cap >= 0 && raw_c && N >= 2 && rgb_dev && disp_dev, "bad arguments");
+  if (cap == 0) return NS_OK;
+  fix_last_sample_kernel<<<ns::ew_grid(cap, 256), 256, 0, ns::as_stream(stream)>>>(
+      rec_dev, count_dev, cap, reinterpret_cast<const float4*>(raw_c), N, white_bkgd, rgb_dev, rgb_stride, disp_dev, disp_stride,
+      weights_dev);
+  NS_LAUNCH_CHECK();
+  return NS_OK;
+}
+
 int ns_patch_sigma_last(float* raw_dev, const float* raw_last_dev, int64_t R, int N, void* stream) {
   NS_REQUIRE(R >= 0 && N >= 1 && raw_dev && raw_last_dev, "bad arguments");
   if (R == 0) return NS_OK;

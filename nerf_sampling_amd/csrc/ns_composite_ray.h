@@ -120,6 +120,13 @@ __device__ __forceinline__ float rcp_tu(float x) { return __builtin_amdgcn_rcpf(
 struct ChunkLocal {
   float alpha, cr, cg, cb, p, excl;
 };
+// raw2alpha (nerf_utils.py:27-42) and the colour sigmoid of one sample (also evaluated by the selective guard's fix-up kernel:
+// one definition, one rounding)
+__device__ __forceinline__ float sample_alpha(float sigma, float dist) {
+  const float alpha = 1.0f - exp_tu(-fmaxf(sigma, 0.0f) * dist);
+  return (sigma != sigma) ? sigma : alpha;      // relu(NaN) is NaN in torch
+}
+__device__ __forceinline__ float sample_colour(float x) { return rcp_tu(1.0f + exp_tu(-x)); }
 template <int SW>
 __device__ __forceinline__ ChunkLocal chunk_local(bool ok, int sub, float4 q, float dist_raw, float norm, float noise, bool has_noise) {
   ChunkLocal L;
@@ -128,11 +135,10 @@ __device__ __forceinline__ ChunkLocal chunk_local(bool ok, int sub, float4 q, fl
     const float dist = dist_raw * norm;
     float sigma = q.w;
     if (has_noise) sigma += noise;
-    L.alpha = 1.0f - exp_tu(-fmaxf(sigma, 0.0f) * dist);
-    if (sigma != sigma) L.alpha = sigma;  // relu(NaN) is NaN in torch
-    L.cr = rcp_tu(1.0f + exp_tu(-q.x));
-    L.cg = rcp_tu(1.0f + exp_tu(-q.y));
-    L.cb = rcp_tu(1.0f + exp_tu(-q.z));
+    L.alpha = sample_alpha(sigma, dist);
+    L.cr = sample_colour(q.x);
+    L.cg = sample_colour(q.y);
+    L.cb = sample_colour(q.z);
   }
   // inclusive product scan of (1 - alpha + 1e-10) over the SW lanes of this chunk
   const float keep = ok ? (1.0f - L.alpha) + 1e-10f : 1.0f;
@@ -152,10 +158,11 @@ __device__ __forceinline__ float chunk_product(const ChunkLocal& L) {
 template <int SW>
 __device__ __forceinline__ void composite_chunk(RayAccum& A, bool ok, int sub, float4 q, float zi, float dist_raw,
                                                 float norm, float noise, bool has_noise, float& alpha_out,
-                                                float& w_out) {
+                                                float& w_out, float* T_out = nullptr) {
   const ChunkLocal L = chunk_local<SW>(ok, sub, q, dist_raw, norm, noise, has_noise);
   const float T = A.carry * L.excl;
   const float w = L.alpha * T;
+  if (T_out) *T_out = T;
   if constexpr (SW == 64) A.carry = A.carry * chunk_product(L);     // (shorter segments are whole rays: nothing is carried)
   if (ok) {
     A.r += w * L.cr; A.g += w * L.cg; A.b += w * L.cb;
@@ -179,11 +186,30 @@ __device__ __forceinline__ void finish_totals(RayAccum& A, int white_bkgd, float
   disp = rcp_tu((q != q) ? q : fmaxf(1e-10f, q));    // torch.max(1e-10, q) propagates NaN
   if (white_bkgd) { A.r += 1.0f - A.acc; A.g += 1.0f - A.acc; A.b += 1.0f - A.acc; }
 }
-// a ray of ONE chunk: the last lane of each SW-lane group ends up with the ray's totals in A and its disparity in `disp`
+// a ray of ONE chunk: the last lane of each SW-lane group ends up with the ray's totals in A and its disparity in `disp`.
+// The share of lane SW - 1 -- the ray's LAST sample when N == SW, the one composited with dist = 1e10 -- joins the sums last:
+// totals = tree(lanes 0 .. SW - 2) + share(SW - 1).  The selective guard (ns_render_args::guard_threshold) re-evaluates that one
+// sample after the kernel and repeats exactly this addition from the tree sums (`tree`, if asked for) it was handed.
 template <int SW>
-__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp, int sub) {
+__device__ __forceinline__ void composite_finish(RayAccum& A, int white_bkgd, float& disp, int sub, RayAccum* tree = nullptr) {
+  const RayAccum own = A;
+  if (sub == SW - 1) { A.r = 0.0f; A.g = 0.0f; A.b = 0.0f; A.depth = 0.0f; A.acc = 0.0f; }
   reduce_sums<SW>(A, sub);
+  if (tree) *tree = A;
+  A.r = A.r + own.r; A.g = A.g + own.g; A.b = A.b + own.b; A.depth = A.depth + own.depth; A.acc = A.acc + own.acc;
   finish_totals(A, white_bkgd, disp);
+}
+// ... and the fix-up's side of it: the ray's totals from the tree sums, the transmittance T entering the last sample, that
+// sample's raw colour, depth and distance, and its re-evaluated sigma (the operations of composite_chunk + composite_finish)
+__device__ __forceinline__ void recomposite_last(RayAccum& A /* in: tree sums, out: totals */, float T, float qx, float qy, float qz,
+                                                 float sigma, float z, float dist, int white_bkgd, float& disp, float& w_out) {
+  const float w = sample_alpha(sigma, dist) * T;
+  RayAccum own;
+  own.r = 0.0f + w * sample_colour(qx); own.g = 0.0f + w * sample_colour(qy); own.b = 0.0f + w * sample_colour(qz);
+  own.depth = 0.0f + w * z; own.acc = 0.0f + w;
+  A.r = A.r + own.r; A.g = A.g + own.g; A.b = A.b + own.b; A.depth = A.depth + own.depth; A.acc = A.acc + own.acc;
+  finish_totals(A, white_bkgd, disp);
+  w_out = w;
 }
 
 // A ray of SEVERAL 64-sample chunks (N > 64): every chunk's sums are reduced on their own and the chunk totals are added in

@@ -52,6 +52,13 @@ struct Nerf16Args {
   // groups -- lcm(group samples, N) samples, whole rays -- before it jumps, so that a ray's chunks meet in one workgroup and
   // the transmittance / sums of the ray that is open at a group boundary carry over in LDS
   int m_chunks, sg_groups;
+  // the selective guard (single-chunk rays): a ray whose own sigma of the last sample is within fix_thr of zero -- where the step
+  // alpha = step(sigma) could flip under the 16-bit rounding -- leaves a 16-float record {tree sums r g b depth acc, T, raw rgb of
+  // the last sample, its z and dist, ray index lo / hi} at slot atomicAdd(fix_count) of fix_rec (ns_fix_last_sample re-evaluates
+  // sigma through the fp32-grade handle and repeats the last addition)
+  float fix_thr;
+  uint32_t* fix_count;
+  float* fix_rec;
 };
 // the five-tile production kernel (PROD, 80 samples per wave): defined in the NS_OB16_TU_T5 unit
 int launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t stream);
@@ -639,17 +646,24 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
           const v2f zd = *czd_at(par, i);
           float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
           if (a.sig_last && (le & (SW - 1)) == SW - 1) q.w = *csig_at(par, i / SW);      // the guard pass's sigma_last
-          nscomp::RayAccum A;
-          float alpha, w, disp;
+          nscomp::RayAccum A, tree;
+          float alpha, w, disp, Tr;
           const int sub = le & (SW - 1);
-          nscomp::composite_chunk<SW>(A, ok, sub, q, zd.x, zd.y, 1.0f, 0.0f, false, alpha, w);
+          nscomp::composite_chunk<SW>(A, ok, sub, q, zd.x, zd.y, 1.0f, 0.0f, false, alpha, w, &Tr);
           if (ok && a.weights) a.weights[s] = w;
-          nscomp::composite_finish<SW>(A, a.white_bkgd, disp, sub);
+          nscomp::composite_finish<SW>(A, a.white_bkgd, disp, sub, &tree);
           if (ok && sub == SW - 1) {
             const int64_t r = s / SW;      // N == SW
             float* prgb = a.rgb + r * a.rgb_stride;
             prgb[0] = A.r; prgb[1] = A.g; prgb[2] = A.b;
             a.disp[r * a.disp_stride] = disp;
+            if (a.fix_rec && __builtin_fabsf(q.w) < a.fix_thr) {      // (a NaN sigma compares false: a NaN ray stays NaN)
+              float* rec = a.fix_rec + static_cast<size_t>(atomicAdd(a.fix_count, 1u)) * 16;
+              reinterpret_cast<float4*>(rec)[0] = make_float4(tree.r, tree.g, tree.b, tree.depth);
+              reinterpret_cast<float4*>(rec)[1] = make_float4(tree.acc, Tr, q.x, q.y);
+              reinterpret_cast<float4*>(rec)[2] = make_float4(q.z, zd.x, zd.y, __builtin_bit_cast(float, static_cast<uint32_t>(r)));
+              rec[12] = __builtin_bit_cast(float, static_cast<uint32_t>(static_cast<uint64_t>(r) >> 32));
+            }
           }
         };
         for (int c = wave; c < T; c += NWAVES) {
@@ -741,7 +755,7 @@ int nsob16::launch_prod_t5(int dtype, bool embedded, Nerf16Args& a, hipStream_t 
 #else
 int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                       float* raw_dev, hipStream_t stream);
+                       float* raw_dev, hipStream_t stream, const uint32_t* count_dev);
 
 // which (network, sample count) pairs the kernel composites itself (see Nerf16Args::comp)
 bool ns_nerf_can_composite(const ns_weights* net, int N) {
@@ -766,7 +780,7 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
     }
   }
   if (net->dtype == NS_DTYPE_F16X3)   // split fp16 operands: ns_nerf_mlp_x3.hip
-    return ns_nerf_forward_x3(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, x90_dev, S, N, raw_dev, stream);
+    return ns_nerf_forward_x3(net, pts_dev, o_dev, d_dev, z_dev, viewdirs_dev, x90_dev, S, N, raw_dev, stream, nullptr);
   if (ob16_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
                   ob16_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs));
@@ -788,6 +802,13 @@ int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const floa
     a.white_bkgd = comp->white_bkgd;
     a.rgb = comp->rgb_dev; a.rgb_stride = comp->rgb_stride; a.disp = comp->disp_dev; a.disp_stride = comp->disp_stride;
     a.weights = comp->weights_dev; a.z_out = comp->z_out_dev; a.pts_out = comp->pts_out_dev;
+    if (comp->fix_rec_dev) {
+      if (N > 64 || comp->sigma_last_dev) {
+        ns::set_error("the selective guard serves rays of one chunk (N <= 64) and excludes the every-ray guard's sigma array");
+        return NS_E_INVALID;
+      }
+      a.fix_thr = comp->fix_thr; a.fix_count = comp->fix_count_dev; a.fix_rec = comp->fix_rec_dev;
+    }
     a.sig_last = comp->sigma_last_dev;
   }
   const bool emb = x90_dev != nullptr;

@@ -71,6 +71,8 @@ struct NerfX3Args {
   int64_t S;
   int N;
   float* raw;
+  const uint32_t* count_dev;   // NULL, or the number of samples to evaluate, read by the kernel (<= S: the selective guard pass
+                               // launches for its capacity and the device knows how many rays were flagged)
 };
 
 // PROD: the production network (8 x 256, skips = [4], view directions) as straight-line code over the generated layer
@@ -86,6 +88,12 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
+  int64_t S_ = a.S;
+  if (a.count_dev) {           // (workgroup-uniform: every wave reads the same word)
+    const int64_t c = static_cast<int64_t>(*a.count_dev);
+    if (c < S_) S_ = c;
+  }
+  if (S_ <= 0) return;
 
   // LDS: [weight ring][bias image][embedding stash: per wave T x 3 blocks x 1 KiB][input staging: per wave 10 x 256 B]
   float* bias_lds = reinterpret_cast<float*>(smem + PipeT::kLdsBytes);
@@ -108,13 +116,13 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
   PipeT ring;
   ring.init(a.stream, smem, a.n_slabs, wave, lane);
 
-  const int64_t n_tiles = (a.S + 15) / 16;
+  const int64_t n_tiles = (S_ + 15) / 16;
   const int64_t n_groups = (n_tiles + NWAVES * T - 1) / (NWAVES * T);
   // sample held by lane `l16` (0..15) of tile t of this wave in group grp; clamped to a real sample
   auto sample_of = [&](int64_t grp, int t, int l16, bool& valid) -> int64_t {
     const int64_t sidx = ((grp * NWAVES + wave) * T + t) * 16 + l16;
-    valid = sidx < a.S;
-    return valid ? sidx : a.S - 1;
+    valid = sidx < S_;
+    return valid ? sidx : S_ - 1;
   };
   // Inputs of the NEXT group are fetched right after layer 0 of the current one by LDS-DMA (no registers held across
   // the network): lane j of the wave fetches the ten values of the j-th of the wave's 64 consecutive samples.
@@ -123,7 +131,7 @@ nerf_mlp_x3_kernel(NerfX3Args a) {
     if constexpr (!EMBEDDED) {
       bool valid;
       const int64_t sidx = sample_of(grp, (lane >> 4) % T, lane & 15, valid);   // (upper lanes re-fetch, harmlessly)
-      const int64_t ray = a.S <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
+      const int64_t ray = S_ <= 0x7fffffff ? static_cast<int64_t>(static_cast<uint32_t>(sidx) / static_cast<uint32_t>(a.N))
                                             : sidx / a.N;
       auto put = [&](int slot, const float* src) {
         lds_dma4(src, stage_base + slot * 256);
@@ -324,7 +332,7 @@ int launch(NerfX3Args& a, hipStream_t stream) {
 // called by ns_nerf_forward_ob16 for NS_DTYPE_F16X3 handles (arguments validated by its callers)
 int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                        const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
-                       float* raw_dev, hipStream_t stream) {
+                       float* raw_dev, hipStream_t stream, const uint32_t* count_dev) {
   if (x3_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs) != static_cast<int>(net->n_slabs)) {
     ns::set_error("ns_nerf_forward: packed stream has %u slabs, kernel program expects %d", net->n_slabs,
                   x3_program_slabs(net->width, net->depth, net->skip_mask, net->use_viewdirs));
@@ -336,7 +344,7 @@ int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float*
   a.D = net->depth; a.skip_mask = net->skip_mask; a.use_viewdirs = net->use_viewdirs; a.out_ch = net->out_ch;
   a.x_stride = net->use_viewdirs ? 90 : 63;
   a.pts = pts_dev; a.o = o_dev; a.d = d_dev; a.z = z_dev; a.viewdirs = viewdirs_dev; a.x90 = x90_dev;
-  a.S = S; a.N = N; a.raw = raw_dev;
+  a.S = S; a.N = N; a.raw = raw_dev; a.count_dev = count_dev;
   const bool emb = x90_dev != nullptr, wide = net->width == 256;
   if (wide && net->depth == 8 && net->skip_mask == (1u << 4) && net->use_viewdirs && !ns::debug_flags().generic_kernels)
     return emb ? launch<8, true, true>(a, stream) : launch<8, false, true>(a, stream);   // the production network

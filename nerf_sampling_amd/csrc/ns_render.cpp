@@ -6,6 +6,9 @@
 int ns_nerf_forward_ob16(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
                          const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
                          float* raw_dev, hipStream_t stream, const ns_composite_args* comp);
+int ns_nerf_forward_x3(const ns_weights* net, const float* pts_dev, const float* o_dev, const float* d_dev,
+                       const float* z_dev, const float* viewdirs_dev, const float* x90_dev, int64_t S, int N,
+                       float* raw_dev, hipStream_t stream, const uint32_t* count_dev);
 
 namespace {
 
@@ -32,8 +35,7 @@ Layout layout(int64_t R, int N) {
 
 // The guard pass: the last sample of every ray through a second, fp32-grade (F16X3) handle of the same network; its raw
 // lands in raw_last [R,4].  (nerf_utils.py:836-865 composites that sample with dist = 1e10, sampling_trainer.py:176-180.)
-int guard_pass(const ns_render_args* a, const float* o, const float* d, const float* view, const float* mean, int64_t R,
-               int N, float* z_last, float* raw_last, void* stream) {
+int guard_check(const ns_render_args* a, int N) {
   const ns_weights* gnet = a->nerf_guard;
   if (!(gnet->kind == NS_KIND_NERF && gnet->out_ch == 4 && gnet->use_viewdirs && gnet->width == a->nerf->width &&
         gnet->depth == a->nerf->depth && gnet->skip_mask == a->nerf->skip_mask)) {
@@ -44,7 +46,14 @@ int guard_pass(const ns_render_args* a, const float* o, const float* d, const fl
     ns::set_error("nerf_guard: the guard pass is defined for uniform placement with n_samples >= 2");
     return NS_E_UNSUPPORTED;
   }
-  int rc = ns_place_last_sample(mean, R, N, a->std_, z_last, stream);
+  return NS_OK;
+}
+int guard_pass(const ns_render_args* a, const float* o, const float* d, const float* view, const float* mean, int64_t R,
+               int N, float* z_last, float* raw_last, void* stream) {
+  const ns_weights* gnet = a->nerf_guard;
+  int rc = guard_check(a, N);
+  if (rc != NS_OK) return rc;
+  rc = ns_place_last_sample(mean, R, N, a->std_, z_last, stream);
   if (rc != NS_OK) return rc;
   return ns_nerf_forward(gnet, nullptr, o, d, z_last, view, R, 1, raw_last, stream);
 }
@@ -125,7 +134,8 @@ int ns_render_fused_supported(const ns_weights* nerf, int mode, int N) {
 
 int64_t ns_render_fused_workspace_bytes(int64_t R) {
   if (R < 0) return 0;
-  return 3 * align256(R * 12) + 2 * align256(R * 4) + align256(R * 16);   // o, d, viewdirs | DepthNet depth | guard: z_last, raw_last
+  // o, d, viewdirs | DepthNet depth | guard: z_last, raw_last | selective guard: counter, records, compact o, d, viewdirs
+  return 3 * align256(R * 12) + 2 * align256(R * 4) + align256(R * 16) + 256 + align256(R * 64) + 3 * align256(R * 12);
 }
 
 int ns_render_rays_fused(const ns_render_args* a, void* stream) {
@@ -170,9 +180,18 @@ int ns_render_rays_fused(const ns_render_args* a, void* stream) {
   c.rgb_dev = a->rgb_dev; c.rgb_stride = a->rgb_stride ? a->rgb_stride : 3;
   c.disp_dev = a->disp_dev; c.disp_stride = a->disp_stride ? a->disp_stride : 1;
   c.weights_dev = a->weights_dev; c.z_out_dev = a->z_dev; c.pts_out_dev = a->pts_dev;
-  if (a->nerf_guard) {     // (before the event pair: the pair times the fused kernel alone)
-    float* z_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + align256(R * 4));
-    float* raw_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + 2 * align256(R * 4));
+  float* z_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + align256(R * 4));
+  float* raw_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + 2 * align256(R * 4));
+  char* fix = ws + 3 * align256(R * 12) + 2 * align256(R * 4) + align256(R * 16);
+  const bool selective = a->nerf_guard && a->guard_threshold > 0.0f && a->N <= 64;
+  if (selective) {         // the kernel flags the rays itself; their last samples are re-evaluated after it
+    rc = guard_check(a, a->N);
+    if (rc != NS_OK) return rc;
+    c.fix_thr = a->guard_threshold;
+    c.fix_count_dev = reinterpret_cast<uint32_t*>(fix);
+    c.fix_rec_dev = reinterpret_cast<float*>(fix + 256);
+    NS_HIP(hipMemsetAsync(fix, 0, 256, ns::as_stream(stream)));
+  } else if (a->nerf_guard) {     // (before the event pair: the pair times the fused kernel alone)
     rc = guard_pass(a, o, d, view, mean, R, a->N, z_last, raw_last, stream);
     if (rc != NS_OK) return rc;
     c.sigma_last_dev = raw_last;
@@ -183,6 +202,19 @@ int ns_render_rays_fused(const ns_render_args* a, void* stream) {
   ns::prod_tiles_hint() = 0;
   if (rc != NS_OK) return rc;
   if (a->ev_mlp_end) NS_HIP(hipEventRecord(static_cast<hipEvent_t>(a->ev_mlp_end), ns::as_stream(stream)));
+  if (selective) {
+    float* o_c = reinterpret_cast<float*>(fix + 256 + align256(R * 64));
+    float* d_c = reinterpret_cast<float*>(fix + 256 + align256(R * 64) + align256(R * 12));
+    float* v_c = reinterpret_cast<float*>(fix + 256 + align256(R * 64) + 2 * align256(R * 12));
+    rc = ns_fix_gather(c.fix_rec_dev, c.fix_count_dev, R, o, d, view, o_c, d_c, v_c, z_last, stream);
+    if (rc != NS_OK) return rc;
+    rc = ns_nerf_forward_x3(a->nerf_guard, nullptr, o_c, d_c, z_last, v_c, nullptr, R, 1, raw_last, ns::as_stream(stream),
+                            c.fix_count_dev);
+    if (rc != NS_OK) return rc;
+    rc = ns_fix_last_sample(c.fix_rec_dev, c.fix_count_dev, R, raw_last, a->N, a->white_bkgd, c.rgb_dev, c.rgb_stride, c.disp_dev,
+                            c.disp_stride, a->weights_dev, stream);
+    if (rc != NS_OK) return rc;
+  }
   return NS_OK;
 }
 

@@ -35,7 +35,18 @@ struct ns_composite_args {
   float* pts_out_dev;      // [R,N,3] or NULL
   const float* sigma_last_dev;   // NULL, or [R,4] raw of every ray's LAST sample from the guard pass: its sigma (element 3)
                                  // replaces the kernel's own for that sample (ns_render_args::nerf_guard)
+  // the selective guard (ns_render_args::guard_threshold > 0): records of the rays whose own |sigma_last| < fix_thr (16 floats
+  // each, Nerf16Args::fix_rec), counted in *fix_count_dev (zeroed by the caller)
+  float fix_thr;
+  uint32_t* fix_count_dev;
+  float* fix_rec_dev;
 };
+// the selective guard's two small kernels (ns_composite.hip): compact inputs of the flagged rays' last samples for the fp32-grade
+// network; then the flagged pixels from the records and the re-evaluated sigma (raw_c [.,4], element 3)
+int ns_fix_gather(const float* rec_dev, const uint32_t* count_dev, int64_t cap, const float* o_dev, const float* d_dev,
+                  const float* view_dev, float* o_c, float* d_c, float* view_c, float* z_c, void* stream);
+int ns_fix_last_sample(const float* rec_dev, const uint32_t* count_dev, int64_t cap, const float* raw_c, int N, int white_bkgd,
+                       float* rgb_dev, int64_t rgb_stride, float* disp_dev, int64_t disp_stride, float* weights_dev, void* stream);
 // internal helpers of the guard pass (ns_rays.hip, ns_composite.hip)
 int ns_place_last_sample(const float* mean_dev, int64_t R, int N, float std_, float* z_last_dev, void* stream);
 int ns_patch_sigma_last(float* raw_dev, const float* raw_last_dev, int64_t R, int N, void* stream);

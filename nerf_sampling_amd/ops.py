@@ -67,11 +67,19 @@ def depthnet_dtype_for(name: Optional[str] = None) -> str:
 # on, the DepthNet runs on split-fp16 operands ("f16x3", fp32-grade) and that one sample per ray is evaluated a second time
 # through an "f16x3" packing of the field (ns_render_args::nerf_guard); the other N - 1 samples keep the fast path.
 _psnr_guard = False
+# Which rays the guard re-evaluates (ns_render_args::guard_threshold): only those whose own 16-bit sigma of the last sample lies
+# within this distance of zero -- a sigma beyond it composites to alpha = 0 or 1 whatever its last bits are.  16 is > 30 x the
+# rms bf16 error of sigma_last on the production network (bench.py: sigma_last_err_rms ~ 0.5); 0 = every ray.
+_guard_threshold = 16.0
 
 
-def set_psnr_guard(on: bool) -> None:
-    global _psnr_guard
+def set_psnr_guard(on: bool, threshold: Optional[float] = None) -> None:
+    global _psnr_guard, _guard_threshold
     _psnr_guard = bool(on)
+    if threshold is not None:
+        if not threshold >= 0.0:
+            raise ValueError("guard threshold must be >= 0 (0 = every ray)")
+        _guard_threshold = float(threshold)
 
 
 def psnr_guard() -> bool:
@@ -441,7 +449,8 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
                          near: float = 2.0, far: float = 6.0, sphere_radius: float = 2.0,
                          white_bkgd: bool = True, extras: bool = False, workspace: Optional[RenderWorkspace] = None,
                          device="cuda", mlp_events=None, shard: Optional[Tensor] = None,
-                         one_kernel: Optional[bool] = None, guard: Optional[PackedWeights] = None):
+                         one_kernel: Optional[bool] = None, guard: Optional[PackedWeights] = None,
+                         guard_threshold: Optional[float] = None):
     """DepthNet -> placement -> NeRF MLP -> compositing as one C call.
 
     rays = (o, d, viewdirs) device tensors, or camera = (H, W, K, c2w, row0, row1) to generate
@@ -456,6 +465,9 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     composites with dist = 1e10, so that alpha = step(sigma) -- is then evaluated a second time through it and its sigma
     replaces the 16-bit one (R of the R * N samples; uniform placement only).  Pair it with an "f16x3" DepthNet handle:
     the two together are the PSNR guard of the 16-bit paths (see psnr_guard_handles).
+    ``guard_threshold`` (one-kernel renderer, n_samples <= 64): None = the module setting (set_psnr_guard, 16.0); > 0 = only the
+    rays whose own sigma of the last sample lies within it of zero are re-evaluated, after the kernel, on a compacted list
+    (the same bits as the every-ray guard wherever |sigma16 - sigma32| stays below it); 0 = every ray, before the kernel.
     """
     lib = _lib.load()
     a = _lib.RenderArgs()
@@ -514,6 +526,7 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
         a.ev_mlp_begin, a.ev_mlp_end = mlp_events[0].handle, mlp_events[1].handle
     if guard is not None:
         a.nerf_guard = guard.handle
+        a.guard_threshold = float(_guard_threshold if guard_threshold is None else guard_threshold)
     if use_fused:
         check(lib.ns_render_rays_fused(C.byref(a), _stream(device)), "ns_render_rays_fused")
     else:

@@ -90,12 +90,13 @@ class FrameRenderer:
 
 def hip_row_renderer(depthnet, nerf, H: int, W: int, K, n_samples: int, mode: str, std: float, near: float = 2.0,
                      far: float = 6.0, sphere_radius: float = 2.0, device="cuda", events: Optional[list] = None,
-                     max_events: int = 128, one_kernel: Optional[bool] = None, guard=None):
+                     max_events: int = 128, one_kernel: Optional[bool] = None, guard=None, guard_threshold: Optional[float] = None):
     """render_rows callable over the fused HIP path.  ``events``: list the (begin, end) hipEvent pair of the
     NeRF-MLP kernel of each call is appended to (bench.py's live roofline timing; the caller clears the list to
     start a new measurement).  At most ``max_events`` calls are timed per measurement.  ``one_kernel``: as in
     ops.render_rays_depthnet (None: the one-kernel renderer whenever the configuration supports it); ``guard``: the field
-    packed "f16x3" for the PSNR guard pass (ops.render_rays_depthnet), or None."""
+    packed "f16x3" for the PSNR guard pass (ops.render_rays_depthnet), or None; ``guard_threshold``: which rays it re-evaluates
+    (None: the module setting, 0: every ray)."""
     from . import ops
 
     ws = ops.RenderWorkspace()
@@ -111,7 +112,8 @@ def hip_row_renderer(depthnet, nerf, H: int, W: int, K, n_samples: int, mode: st
                 events.append(ev)
         out = ops.render_rays_depthnet(depthnet, nerf, camera=(H, W, K, c2w, row0, row1), n_samples=n_samples,
                                        mode=mode, std=std, near=near, far=far, sphere_radius=sphere_radius,
-                                       workspace=ws, device=device, mlp_events=ev, shard=shard, one_kernel=one_kernel, guard=guard)
+                                       workspace=ws, device=device, mlp_events=ev, shard=shard, one_kernel=one_kernel, guard=guard,
+                                       guard_threshold=guard_threshold)
         return out["rgb"], out["disp"]
 
     return render_rows

@@ -393,12 +393,24 @@ def test_psnr_guard_replaces_sigma_of_the_last_sample(gpu_modules, dtype):
         patched[:, -1, 3] = raw_last[:, 0, 3]
         assert float((patched[:, -1, 3] - raw[:, -1, 3]).abs().max()) > 0       # the guard changes something
         rgb, disp, _acc, _depth, _al, weights = ops.raw2outputs(patched, z, d, None, True)
-        for one in (True, False):
+        for one, thr in ((True, 0.0), (False, 0.0), (True, None), (True, 2.0)):
+            # thr 0: every ray before the kernel.  None (the module's 16) / 2: the one-kernel renderer flags the rays whose own
+            # sigma_last is within thr of zero, re-evaluates those after the kernel and re-adds their last share -- the same bits
+            # wherever the 16-bit and the fp32-grade sigma differ by less than thr (n = 192: several chunks, every ray as before)
             out = ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=n, mode="uniform", std=0.1,
-                                           extras=True, one_kernel=one, guard=gw)
-            assert torch.equal(out["rgb"].view(torch.int32), rgb.view(torch.int32)), (n, one, (out["rgb"] - rgb).abs().max().item())
-            assert torch.equal(out["disp"].view(torch.int32), disp.view(torch.int32)) and torch.equal(out["z"], z), (n, one)
-            assert torch.equal(out["weights"].view(torch.int32), weights.view(torch.int32)), (n, one)
+                                           extras=True, one_kernel=one, guard=gw, guard_threshold=thr)
+            lim = 16.0 if thr is None else thr
+            same = torch.ones(rgb.shape[0], dtype=torch.bool, device="cuda")
+            if lim > 0 and n <= 64:
+                s16, s32 = raw[:, -1, 3], raw_last[:, 0, 3]
+                same = ((s16 > 0) == (s32 > 0)) | (s16.abs() < lim)          # unflagged rays whose step flips keep the 16-bit one
+                assert float(same.float().mean()) > (0.999 if thr is None else 0.98), (n, thr, float(same.float().mean()))
+                if thr == 2.0:
+                    assert int((s16.abs() < lim).sum()) < rgb.shape[0] // 2      # ... and the flagged set is a minority
+            tag = (n, one, thr)
+            assert torch.equal(out["rgb"][same].view(torch.int32), rgb[same].view(torch.int32)), (tag, (out["rgb"] - rgb).abs().max().item())
+            assert torch.equal(out["disp"][same].view(torch.int32), disp[same].view(torch.int32)) and torch.equal(out["z"], z), tag
+            assert torch.equal(out["weights"][same].view(torch.int32), weights[same].view(torch.int32)), tag
     with pytest.raises((NotImplementedError, ValueError)):                       # the guard pass is defined for uniform placement
         ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=8, mode="gaussian", std=0.1, guard=gw)
     with pytest.raises(ValueError):                                              # ... and for another packing of the SAME network
