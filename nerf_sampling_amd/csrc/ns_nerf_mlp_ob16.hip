@@ -336,6 +336,9 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
               return *reinterpret_cast<const float __attribute__((address_space(3)))*>(
                   static_cast<uintptr_t>(stage_base + slot * kStageRow + i * 4));
             };
+            // every staged value of the pass in one burst, ahead of the arithmetic (slot 10 holds the next depth, the guard's
+            // sigma, or nothing: read whatever is there, used only where it is defined)
+            const float m_or_z = st(6), d0 = st(3), d1 = st(4), d2 = st(5), s10 = st(10);
             const int ig = wave * (16 * T) + i;                             // the sample's index within the group
             const bool valid = ig < rem;
             int j, ray_in_group;                                            // (a sample past the end: any in-range j, never used)
@@ -346,16 +349,13 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
               ray_in_group = (x >= a.N) + (x >= 2 * a.N) + (x >= 3 * a.N);
               j = x - ray_in_group * a.N;
             }
-            float zz = st(6), znext;
+            float zz = m_or_z, znext = s10;
             if (a.comp == 2)        // sample_points_around_mean("uniform"): depths j and j + 1 of the ray from its mean
-              nsplace::uniform_z_pair(zz, a.std_, a.lin_step, a.N - 1, j, zz, znext);
-            else
-              znext = st(10);
+              nsplace::uniform_z_pair(m_or_z, a.std_, a.lin_step, a.N - 1, j, zz, znext);
             const float dist_raw = (j < a.N - 1) ? znext - zz : 1e10f;      // sampling_trainer.py:176-180
-            const float d0 = st(3), d1 = st(4), d2 = st(5);
             *czd_at(par, ig) = v2f{zz, dist_raw * nscomp::ray_norm(d0, d1, d2)};
             // the guard pass's sigma of this ray's last sample: one slot per ray of the group
-            if (a.sig_last && j == a.N - 1) *csig_at(par, ray_in_group) = st(10);
+            if (a.sig_last && j == a.N - 1) *csig_at(par, ray_in_group) = s10;
             if (valid && (a.z_out || a.pts_out)) {
               const int64_t sidx = grp * GS + ig;
               if (a.z_out) a.z_out[sidx] = zz;

@@ -43,16 +43,25 @@ __device__ __forceinline__ float uniform_z(float m, float std_, float step, int 
 
 // z[j] and z[j + 1] of the same ray at once (the one-kernel renderer needs a sample's depth and the distance to the next one):
 // the three grid values a_{j-1}, a_j, a_{j+1} are evaluated once, the selections are those of uniform_z -- the same bits.
+// Written without branches (both sides of every choice are computed, then selected: the compiler otherwise masks EXEC around each
+// two-instruction arm), and with the integer -> float conversions shared: float(k) for k = j - 1, j, j + 1 and float(steps - k - 1)
+// are differences of small exact integers, so fj -+ 1 and fs1 - fk are the very values the conversions give.
 __device__ __forceinline__ void uniform_z_pair(float m, float std_, float step, int steps, int j, float& z, float& z_next) {
   const int half = steps / 2;
-  auto grid = [&](int k) {             // m + linspace_step(-std, std, step, steps, k)
-    return m + ((k < half || steps <= 1) ? -std_ + step * static_cast<float>(k) : std_ - step * static_cast<float>(steps - k - 1));
+  const float fj = static_cast<float>(j), fs1 = static_cast<float>(steps - 1);
+  const bool one = steps <= 1;                       // linspace_step returns `start` for a single step
+  auto grid = [&](int k, float fk) {                 // m + linspace_step(-std, std, step, steps, k)
+    const float lo = -std_ + step * fk;
+    const float hi = std_ - step * (fs1 - fk);
+    const bool low = (k < half) | one;
+    return m + (low ? lo : hi);
   };
-  const float am = grid(j - 1), a0 = grid(j), ap = grid(j + 1);       // (out-of-range k: evaluated, never selected)
+  const float am = grid(j - 1, fj - 1.0f), a0 = grid(j, fj), ap = grid(j + 1, fj + 1.0f);   // (out-of-range k: never selected)
   auto pick = [&](int jj, float below, float here) {                   // uniform_z(jj) from a_{jj-1} = below, a_jj = here
-    float v = m;
-    if (jj < steps && here < m) v = here;
-    if (v == m && jj >= 1 && !(below < m)) v = below;
+    const bool c1 = (jj < steps) & (here < m);
+    float v = c1 ? here : m;
+    const bool c2 = (v == m) & (jj >= 1) & !(below < m);
+    v = c2 ? below : v;
     v = fminf(fmaxf(v, 2.0f), 6.0f);
     return (m != m) ? m : v;
   };
