@@ -655,7 +655,7 @@ def main():
                               fine.D, fine.W, 4)
     # HBM bytes per launch of that kernel: from the separate rocprofv3 --pmc passes under profiles/ (PMC counters cannot
     # be read from inside the process); only quoted for the exact workload and build they were collected on
-    tname = "r04_traffic_nerf_mlp.json"
+    tname = "r04f_traffic_nerf_mlp.json"
     tpath = os.path.join(ROOT, "profiles", tname)
     if (world == 1 and args.mode == "depthnet" and args.dtype == "bf16" and args.size == 800 and args.samples == 64
             and not args.chain and os.path.exists(tpath)):
