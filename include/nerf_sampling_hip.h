@@ -248,7 +248,8 @@ int ns_render_rays_depthnet(const ns_render_args* args, void* stream);
  * epilogue by the same wave scan ns_raw2outputs runs: rgb / disp (and z / weights / pts when asked for) are BIT-IDENTICAL
  * to ns_render_rays_depthnet.  Three launches per call (ray generation, DepthNet, the fused kernel); HBM traffic is the
  * rays, 4 B + 16 B per ray and the weight streams.  Supported (ns_render_fused_supported != 0): mode NS_MODE_UNIFORM,
- * a bf16 / f16 NeRF handle with view directions, N a power of two in [2, 64]; anything else returns NS_E_UNSUPPORTED and
+ * a bf16 / f16 NeRF handle with view directions, N a power of two in [2, 64] or a multiple of 64 up to 512 (a ray is then
+ * several 64-sample chunks composited side by side); anything else returns NS_E_UNSUPPORTED and
  * is served by ns_render_rays_depthnet.  Workspace: ns_render_fused_workspace_bytes(R) bytes, 256-byte aligned.        */
 int ns_render_fused_supported(const ns_weights* nerf, int mode, int N);
 int64_t ns_render_fused_workspace_bytes(int64_t R);

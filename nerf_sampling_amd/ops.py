@@ -459,7 +459,7 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     straight into shard[i] (the unit parallel.FrameRenderer all-gathers) and rgb / disp are returned as views of it.
     ``one_kernel``: None (default) = ns_render_rays_fused -- placement, MLP and compositing in ONE persistent kernel, per-sample
     data never in HBM -- whenever the configuration supports it (uniform placement, bf16 / f16 field, n_samples a power of
-    two <= 64), else the five-launch chain ns_render_rays_depthnet; True = require it; False = the chain.  Both produce the
+    two <= 64 or a multiple of 64 up to 512), else the five-launch chain ns_render_rays_depthnet; True = require it; False = the chain.  Both produce the
     same bits.
     ``guard``: the SAME radiance field packed "f16x3" (fp32-grade).  The last sample of every ray -- the one the reference
     composites with dist = 1e10, so that alpha = step(sigma) -- is then evaluated a second time through it and its sigma
@@ -508,7 +508,7 @@ def render_rays_depthnet(depthnet: PackedWeights, nerf: PackedWeights, *, rays=N
     fused_ok = bool(lib.ns_render_fused_supported(nerf.handle, a.mode, N)) and noise is None
     if one_kernel and not fused_ok:
         raise NotImplementedError(f"the one-kernel renderer needs uniform placement, a bf16 / f16 field with view directions and "
-                                  f"n_samples a power of two in [2, 64] (mode {mode!r}, n_samples {N}, dtype {getattr(nerf, 'dtype', '?')})")
+                                  f"n_samples a power of two in [2, 64] or a multiple of 64 up to 512 (mode {mode!r}, n_samples {N}, dtype {getattr(nerf, 'dtype', '?')})")
     use_fused = fused_ok if one_kernel is None else bool(one_kernel)
     nbytes = int(lib.ns_render_fused_workspace_bytes(R) if use_fused else lib.ns_render_workspace_bytes(R, N))
     ws = (workspace or _default_ws).get(nbytes, device)
