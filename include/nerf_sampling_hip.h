@@ -52,7 +52,9 @@ int ns_device_cu_count(void);
 /* Diagnostic switches of the kernel dispatch (tests compare code paths inside one process; no effect on results):
  *   "generic_kernels" 0/1 -- 1: the production network (8 x 256, skips = [4]) runs the generic compiler-scheduled kernels
  *                            instead of the generated instruction streams;
- *   "prod_tiles" 0/4/5    -- tiles per wave of the 16-bit production kernel, 0 = chosen per launch.
+ *   "prod_tiles" 0/4/5    -- tiles per wave of the 16-bit production kernel, 0 = chosen per launch;
+ *   "hier_chain" 0/1      -- 1: ns_render_rays_hierarchical keeps raw [R,N,4] in HBM and composites with ns_raw2outputs instead
+ *                            of in the MLP kernels' epilogues.
  * Initial values come from the environment (NS_OB16_GENERIC, NS_OB16_TILES), read once at first use.              */
 int ns_debug_set(const char* name, int value);
 
