@@ -325,7 +325,7 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
     dn, nf = m["depth"].packed(dtype), m["fine"].packed(dtype)
     o, d, view = ops.get_rays(H, W, K, c2w)[:3]
     mean = ops.depthnet_forward(dn, o, d)
-    for n in (64, 32, 96, 192, 16, 2, 128):
+    for n in (64, 32, 96, 192, 16, 2, 128) + ((256, 512) if scene == "tiny_synth" else ()):   # (512: eight chunks per ray, runs of eight groups)
         pts, z = ops.place_samples(o, d, mean, n, "uniform", 0.1)
         raw = ops.nerf_forward_rays(nf, o, d, z, view)
         rgb, disp, acc, depth, alphas, weights = ops.raw2outputs(raw, z, d, None, True)
@@ -411,6 +411,16 @@ def test_psnr_guard_replaces_sigma_of_the_last_sample(gpu_modules, dtype):
             assert torch.equal(out["rgb"][same].view(torch.int32), rgb[same].view(torch.int32)), (tag, (out["rgb"] - rgb).abs().max().item())
             assert torch.equal(out["disp"][same].view(torch.int32), disp[same].view(torch.int32)) and torch.equal(out["z"], z), tag
             assert torch.equal(out["weights"][same].view(torch.int32), weights[same].view(torch.int32)), tag
+    # explicit rays, an interleaved [R, 4] shard as the output, per-sample outputs asked for: the fix-up kernel writes through the
+    # same strides and patches the last weight
+    shard = torch.empty((o.shape[0], 4), dtype=torch.float32, device="cuda")
+    every = ops.render_rays_depthnet(dn, nf, rays=(o, d, view), n_samples=64, mode="uniform", std=0.1, extras=True, one_kernel=True,
+                                     guard=gw, guard_threshold=0.0)
+    sel = ops.render_rays_depthnet(dn, nf, rays=(o, d, view), n_samples=64, mode="uniform", std=0.1, extras=True, one_kernel=True,
+                                   guard=gw, guard_threshold=1e6, shard=shard)       # every ray is flagged: the capacity case
+    assert torch.equal(shard[:, :3].view(torch.int32), every["rgb"].view(torch.int32)) and sel["rgb"].data_ptr() == shard.data_ptr()
+    assert torch.equal(shard[:, 3].view(torch.int32), every["disp"].view(torch.int32))
+    assert torch.equal(sel["weights"].view(torch.int32), every["weights"].view(torch.int32))
     with pytest.raises((NotImplementedError, ValueError)):                       # the guard pass is defined for uniform placement
         ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=8, mode="gaussian", std=0.1, guard=gw)
     with pytest.raises(ValueError):                                              # ... and for another packing of the SAME network
