@@ -469,15 +469,18 @@ def other_configs(ops, synthetic, nets, params, ref, H, W, K, poses, pose_k, dev
     from nerf_sampling_amd import analytic_scene
     gt_band = analytic_scene.frame(H, W, K, poses[pose_k], r0, r1)[0].reshape(-1, 3)
     # (label, field operands, guarded, timed steps); "guarded" = ops.set_psnr_guard: f16x3 DepthNet + every ray's last sample on f16x3
-    # "guarded": None, or the guard threshold -- 16 (the default): only rays whose own sigma_last is within 16 of zero are
-    # re-evaluated, after the kernel; 0: every ray, before the kernel
-    for label, dtype, guarded, steps in ((f"{headline_dtype} + PSNR guard", headline_dtype, 16.0, 5),
-                                         (f"{headline_dtype} + PSNR guard on every ray", headline_dtype, 0.0, 4),
-                                         ("f16x3", "f16x3", None, 4), ("f32", "f32", None, 3),
-                                         ("f16" if headline_dtype == "bf16" else "bf16",) * 2 + (None, 5)):
-        thr, guarded = guarded, guarded is not None
+    # (label, field operands, guard = None or (DepthNet operands, threshold), timed steps).  The guard (ops.set_psnr_guard): the
+    # DepthNet on "f16x3" (every layer split, the default) or "f16m" (the first three) operands + sigma of the last sample
+    # re-evaluated on f16x3 -- threshold 16: only for the rays whose own sigma there is within 16 of zero, after the kernel; 0: every ray
+    for label, dtype, guard, steps in ((f"{headline_dtype} + PSNR guard", headline_dtype, ("f16x3", 16.0), 5),
+                                       (f"{headline_dtype} + PSNR guard, economy setting (f16m DepthNet: three of its ten layers split)",
+                                        headline_dtype, ("f16m", 16.0), 4),
+                                       (f"{headline_dtype} + PSNR guard on every ray", headline_dtype, ("f16x3", 0.0), 4),
+                                       ("f16x3", "f16x3", None, 4), ("f32", "f32", None, 3),
+                                       ("f16" if headline_dtype == "bf16" else "bf16",) * 2 + (None, 5)):
+        guarded, thr = guard is not None, (guard[1] if guard else None)
         nw = fine.packed(dtype)
-        dw = dn.packed("f16x3" if guarded else ops.depthnet_dtype_for(dtype))
+        dw = dn.packed(guard[0] if guarded else ops.depthnet_dtype_for(dtype))
         gw = fine.packed("f16x3") if guarded else None
         events = []
         t = Timed(H, W, hip_row_renderer(dw, nw, H, W, K, samples, "uniform", 0.1, device=device, events=events, guard=gw,

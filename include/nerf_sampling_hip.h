@@ -39,6 +39,10 @@ extern "C" {
 #define NS_DTYPE_F16X3 3 /* split fp16 operands (x = hi + lo), three v_mfma_f32_16x16x32_f16 per product term: fp32-grade
                           * results (the fp32 parity gates hold) at ~1/3 of the fp16 rate; operands must fit fp16's
                           * range (|w| < 65504, checked at pack time)                                    */
+#define NS_DTYPE_F16M 4  /* DepthNet only, the production 10 x 256 trunk: MIXED fp16 operands -- the first
+                          * NS_F16M_SPLIT_LAYERS trunk layers split as in F16X3 (that is where an fp16 DepthNet loses its depth:
+                          * 90 % of the error's variance), the rest plain F16; 1.6 x the fp16 kernel's MFMAs instead of 3 x */
+#define NS_F16M_SPLIT_LAYERS 3
 
 /* sample placement modes, utils.py:220-244 */
 #define NS_MODE_DEPTH_ONLY 0

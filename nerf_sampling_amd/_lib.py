@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NS_LIB_PATH") or os.path.join(_HERE, "libnerf_sampling_hip.so")
 
 NS_OK = 0
-DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F16X3 = 0, 1, 2, 3
+DTYPE_F32, DTYPE_BF16, DTYPE_F16, DTYPE_F16X3, DTYPE_F16M = 0, 1, 2, 3, 4
 MODE_DEPTH_ONLY, MODE_UNIFORM, MODE_GAUSSIAN = 0, 1, 2
 
 _p = C.c_void_p

@@ -475,7 +475,8 @@ int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, cons
   NS_REQUIRE(out && w && b && hidden_sizes && cat_sizes, "null pointer");
   *out = nullptr;
   if (n_branch < 1 || n_branch > 64 || n_trunk < 1 || n_trunk > 64 ||
-      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3)) {
+      !(dtype == NS_DTYPE_F32 || dtype == NS_DTYPE_BF16 || dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3 ||
+        dtype == NS_DTYPE_F16M)) {
     ns::set_error("ns_pack_depthnet: unsupported network (n_branch=%d n_trunk=%d dtype=%d)", n_branch, n_trunk, dtype);
     return NS_E_UNSUPPORTED;
   }
@@ -501,7 +502,13 @@ int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, cons
   //    to ONE width Wp in {128, 256}: a padded row has zero weights and bias, LeakyReLU(0) = 0 feeds zero columns
   const int W = cmax <= 128 ? 128 : 256, NB = W / 32;
   const int layout = dtype == NS_DTYPE_F32 ? 0 : 16;
-  if (dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3) {   // fp16 operands: refuse what would silently become +-inf
+  const bool mixed = dtype == NS_DTYPE_F16M;
+  if (mixed && !(W == 256 && n_trunk == 10)) {
+    ns::set_error("ns_pack_depthnet: mixed fp16 operands (NS_DTYPE_F16M) are built for the production trunk (ten layers padded to "
+                  "256), got %d layers of width <= %d; use NS_DTYPE_F16X3", n_trunk, cmax);
+    return NS_E_UNSUPPORTED;
+  }
+  if (dtype == NS_DTYPE_F16 || dtype == NS_DTYPE_F16X3 || mixed) {   // fp16 operands: refuse what would silently become +-inf
     bool ok = fits_f16(F32.data(), F32.size());
     for (int i = 1; i < n_trunk && ok; ++i) ok = fits_f16(w[t0 + i], static_cast<size_t>(cat_sizes[i]) * cat_sizes[i - 1]);
     ok = ok && fits_f16(w[t0 + n_trunk], cat_sizes[n_trunk - 1]);
@@ -510,9 +517,31 @@ int ns_pack_depthnet_ex(int n_branch, const int* hidden_sizes, int n_trunk, cons
       return NS_E_UNSUPPORTED;
     }
   }
-  Builder bl(dtype);
+  Builder bl(mixed ? NS_DTYPE_F16 : dtype);
   auto padded_ident = [](int in_f) { return [in_f](int k) { return k < in_f ? k : -1; }; };
-  if (layout == 0) {
+  if (mixed) {
+    // the mixed program (depthnet_mix_kernel): layers 0 .. KX-1 as split (hi, lo) chunks, TWICE in a row -- a wave takes its four
+    // tiles through them two at a time -- then layers KX .. 9 and the head as plain fp16 chunks; one bias image for all
+    const int NSB = W / 16, NKB = W / 32, KX = NS_F16M_SPLIT_LAYERS;
+    auto layer = [&](int i) {
+      if (i == 0)
+        bl.layer_ob16(F32.data(), C0, EIN, NSB,
+                      {{2, [](int k) { return nsmlp::embedN_col16(k, 3, 10); }},
+                       {2, [](int k) { const int c = nsmlp::embedN_col16(k, 3, 10); return c < 0 ? -1 : E3 + c; }},
+                       {4, [](int k) { const int c = nsmlp::embedN_col16(k, 6, 10); return c < 0 ? -1 : 2 * E3 + c; }}});
+      else
+        bl.layer_ob16(w[t0 + i], cat_sizes[i], cat_sizes[i - 1], NSB, {{NKB, padded_ident(cat_sizes[i - 1])}});
+    };
+    bl.add_bias16(fb32.data(), C0, NSB);
+    for (int i = 1; i < n_trunk; ++i) bl.add_bias16(b[t0 + i], cat_sizes[i], NSB);
+    bl.add_bias16(b[t0 + n_trunk], 1, 1);
+    bl.split = true;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int i = 0; i < KX; ++i) layer(i);
+    bl.split = false;
+    for (int i = KX; i < n_trunk; ++i) layer(i);
+    bl.layer_ob16(w[t0 + n_trunk], 1, cat_sizes[n_trunk - 1], 1, {{NKB, padded_ident(cat_sizes[n_trunk - 1])}});
+  } else if (layout == 0) {
     // k-major (fp32): input blocks e_o (2), e_d (2), e_x (4) in the slot order of embed3 / embed6
     auto col3 = [](int k) { return nsmlp::embed3_col(k, 10); };
     bl.add_bias(fb32.data(), C0, NB);

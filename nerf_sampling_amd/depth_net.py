@@ -76,11 +76,13 @@ class DepthNet(nn.Module):
         itself if the weights do not fit fp16's range."""
         if dtype is None:
             name, paired = ops.get_compute_dtype(), ops.depthnet_dtype_for()
-            if paired != name and paired not in self._unpackable:
-                try:
-                    return self.packed(paired)
-                except NotImplementedError:
-                    self._unpackable.add(paired)      # (e.g. weights beyond fp16's range) do not re-fold / re-pack per call
+            # ("f16m" exists for the production trunk only: another shape takes every layer split)
+            for cand in ((paired, "f16x3") if paired == "f16m" else (paired,)):
+                if cand != name and cand not in self._unpackable:
+                    try:
+                        return self.packed(cand)
+                    except NotImplementedError:
+                        self._unpackable.add(cand)    # (e.g. weights beyond fp16's range) do not re-fold / re-pack per call
         else:
             name = dtype
         if name not in self._packed:

@@ -39,9 +39,10 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
               help="MFMA operand precision of the HIP kernels (not in the reference).")
 @click.option("--psnr-guard/--no-psnr-guard", "psnr_guard", default=True, show_default=True,
               help="(not in the reference) This CLI's deliverable is a PSNR file: with a 16-bit --dtype the DepthNet and the "
-                   "last sample of every ray -- the one composited with dist = 1e10 -- run on fp32-grade split-fp16 operands "
-                   "(ops.set_psnr_guard; ~10 % of the frame).  Per-image PSNR then stays within 0.01 dB of the fp32 "
-                   "arithmetic on a 28-30 dB scene; without it the 16-bit paths sit at 0.03-0.13 dB (tools/scene_psnr_sweep.py).")
+                   "last sample of a ray whose density there is near zero -- the one composited with dist = 1e10 -- run on "
+                   "fp32-grade split-fp16 operands (ops.set_psnr_guard; ~4.5 % of the frame).  Per-image PSNR then stays within "
+                   "0.03 dB of the fp32 arithmetic on a 28-30 dB scene; without it the 16-bit paths sit at 0.03-0.26 dB "
+                   "(tools/guard_experiment.py).")
 @click.option("--root", default=os.getcwd(), show_default=True,
               help="Directory holding dataset/ pretrained/ logs/ (the reference uses its package directory).")
 def main(**kw):

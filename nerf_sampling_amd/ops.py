@@ -21,7 +21,8 @@ Tensor = torch.Tensor
 _DTYPES = {"f32": _lib.DTYPE_F32, "fp32": _lib.DTYPE_F32, "float32": _lib.DTYPE_F32,
            "bf16": _lib.DTYPE_BF16, "bfloat16": _lib.DTYPE_BF16,
            "f16": _lib.DTYPE_F16, "fp16": _lib.DTYPE_F16, "float16": _lib.DTYPE_F16,
-           "f16x3": _lib.DTYPE_F16X3}     # split fp16 operands: fp32-grade results on the 16-bit engine
+           "f16x3": _lib.DTYPE_F16X3,     # split fp16 operands: fp32-grade results on the 16-bit engine
+           "f16m": _lib.DTYPE_F16M}       # DepthNet only (production trunk): first three layers split, the rest plain fp16
 _MODES = {"depth_only": _lib.MODE_DEPTH_ONLY, "uniform": _lib.MODE_UNIFORM, "gaussian": _lib.MODE_GAUSSIAN}
 
 _compute_dtype = "f32"
@@ -55,7 +56,7 @@ _DEPTHNET_PAIRING = {"bf16": "f16"}
 def depthnet_dtype_for(name: Optional[str] = None) -> str:
     name = name or _compute_dtype
     if _psnr_guard and name in ("bf16", "f16"):
-        return "f16x3"
+        return _guard_depthnet
     return _DEPTHNET_PAIRING.get(name, name)
 
 
@@ -64,22 +65,33 @@ def depthnet_dtype_for(name: Optional[str] = None) -> str:
 # |delta| 0.13 dB for bf16 + bf16, 0.052 dB for the default bf16 + f16 pairing), and the error has two sources that touch
 # 1/64 of the arithmetic: the DepthNet's depth (it moves a ray's whole sampling window) and sigma of the LAST sample of a
 # ray, which the reference composites with dist = 1e10 (alpha = step(sigma), sampling_trainer.py:176-180).  With the guard
-# on, the DepthNet runs on split-fp16 operands ("f16x3", fp32-grade) and that one sample per ray is evaluated a second time
-# through an "f16x3" packing of the field (ns_render_args::nerf_guard); the other N - 1 samples keep the fast path.
+# on, the DepthNet runs on (partly) split fp16 operands (_guard_depthnet below) and that one sample per ray is evaluated a
+# second time through an "f16x3" packing of the field (ns_render_args::nerf_guard); the other N - 1 samples keep the fast path.
 _psnr_guard = False
 # Which rays the guard re-evaluates (ns_render_args::guard_threshold): only those whose own 16-bit sigma of the last sample lies
 # within this distance of zero -- a sigma beyond it composites to alpha = 0 or 1 whatever its last bits are.  16 is > 30 x the
 # rms bf16 error of sigma_last on the production network (bench.py: sigma_last_err_rms ~ 0.5); 0 = every ray.
 _guard_threshold = 16.0
+# The guard's DepthNet operands.  "f16x3" (the default): every layer on split fp16 operands, fp32-grade depths (z rms 8e-7 on the
+# fitted scene) at 2.9 x the fp16 kernel's time: PSNR(build || fp32) 63-64 dB, every frame and band within 0.03 dB.  "f16m": the
+# first three trunk layers split, the other seven plain fp16 -- the rounding of the first layers' wide-ranged activations is where
+# a TRAINED fp16 DepthNet loses its depth (z rms 8.9e-4 -> 1.2e-4 there; tools/depthnet_mix_check.py) -- at 1.7 x: 50-53 dB, whole
+# frames within 0.03 dB but a 60-row band can read 0.06 (tools/guard_experiment.py, tests/test_scene_psnr.py): the economy setting,
+# built for the production trunk (ten layers, 256 wide; any other shape falls back to "f16x3").
+_guard_depthnet = "f16x3"
 
 
-def set_psnr_guard(on: bool, threshold: Optional[float] = None) -> None:
-    global _psnr_guard, _guard_threshold
+def set_psnr_guard(on: bool, threshold: Optional[float] = None, depthnet: Optional[str] = None) -> None:
+    global _psnr_guard, _guard_threshold, _guard_depthnet
     _psnr_guard = bool(on)
     if threshold is not None:
         if not threshold >= 0.0:
             raise ValueError("guard threshold must be >= 0 (0 = every ray)")
         _guard_threshold = float(threshold)
+    if depthnet is not None:
+        if depthnet not in ("f16m", "f16x3"):
+            raise ValueError("the guard's DepthNet runs on 'f16m' or 'f16x3' operands")
+        _guard_depthnet = depthnet
 
 
 def psnr_guard() -> bool:

@@ -25,9 +25,11 @@ def test_unsupported_network_shapes_raise():
     dn = DepthNet(hidden_sizes=[64, 64], cat_hidden_sizes=[128, 128], multires=6).cuda()   # not the multires the kernel embeds
     with pytest.raises(NotImplementedError):
         dn(torch.zeros(4, 3).cuda(), torch.ones(4, 3).cuda())
-    net = NeRF(D=8, W=96, input_ch=63, input_ch_views=27, use_viewdirs=True).cuda()   # width without a kernel
+    net = NeRF(D=8, W=320, input_ch=63, input_ch_views=27, use_viewdirs=True).cuda()  # wider than the kernels (128 / 256)
     with pytest.raises(NotImplementedError):
         net(torch.zeros(8, 90).cuda())
+    net = NeRF(D=8, W=96, input_ch=63, input_ch_views=27, use_viewdirs=True).cuda()   # narrower: zero-padded to 128 at pack time
+    assert net(torch.zeros(8, 90).cuda()).shape == (8, 4)
     net = NeRF(D=8, W=256, input_ch=21, input_ch_views=27, use_viewdirs=True).cuda()   # not the multires the kernel embeds
     with pytest.raises(NotImplementedError):
         net(torch.zeros(8, 48).cuda())

@@ -1,3 +1,5 @@
+"""Which component of the PSNR guard buys what, per pose of the fitted scene: whole-frame and band scene-PSNR deltas to fp32 arithmetic and
+PSNR(build vs fp32) for the bf16 field with an f16 / f16m / f16x3 DepthNet, with and without the sigma_last guard."""
 import json, math, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -8,7 +10,8 @@ _c, fine, dn, _p = bench.build_modules("shapes_fit", dev)
 H = W = 800
 _, K = synthetic.blender_intrinsics(H, W)
 poses = synthetic.render_poses(40)[:, :3, :4]
-combos = {"f32": ("f32", "f32", False), "plain": ("bf16", "f16", False), "sig_only": ("bf16", "f16", True), "dn_only": ("bf16", "f16x3", False), "full": ("bf16", "f16x3", True)}
+combos = {"f32": ("f32", "f32", False), "plain": ("bf16", "f16", False), "sig_only": ("bf16", "f16", True), "dn_only": ("bf16", "f16x3", False), "full": ("bf16", "f16x3", True),
+          "mix_only": ("bf16", "f16m", False), "mix_full": ("bf16", "f16m", True)}
 out = {}
 for k in (0, 3, 7, 13, 21, 34):
     gt = analytic_scene.frame(H, W, K, poses[k], device="cuda")[0].reshape(-1, 3)
