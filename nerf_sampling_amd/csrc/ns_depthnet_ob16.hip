@@ -221,7 +221,7 @@ depthnet_ob16_kernel(Depth16Args a) {
 
 // ---- MIXED operands (NS_DTYPE_F16M): the first KX trunk layers on split fp16 operands, the rest on plain fp16 --------------
 // Where the fp16 DepthNet loses its depth: per-layer rounding of operands, emulated on the production network's weights
-// (DESIGN section 4.1): the first three layers contribute 90 % of the depth error's variance -- their inputs are the widest-ranged
+// (tools/depthnet_layer_sensitivity.py): the first three layers contribute 90 % of the depth error's variance -- their inputs are the widest-ranged
 // activations of the network -- the last five 3 %.  So the production trunk (ten 256-wide LeakyReLU layers + head) runs its
 // first KX layers as the f16x3 statements (hi + lo operand pairs, three MFMAs per product term: two tiles of 16 rays fill the
 // registers) and layers KX .. 9 as the fp16 statements (four tiles).  A wave therefore takes its four tiles through the split
