@@ -183,7 +183,10 @@ int ns_render_rays_fused(const ns_render_args* a, void* stream) {
   float* z_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + align256(R * 4));
   float* raw_last = reinterpret_cast<float*>(ws + 3 * align256(R * 12) + 2 * align256(R * 4));
   char* fix = ws + 3 * align256(R * 12) + 2 * align256(R * 4) + align256(R * 16);
-  const bool selective = a->nerf_guard && a->guard_threshold > 0.0f && a->N <= 64;
+  // (the fix-up launches the split-operand MLP kernel with a device-side count: another packing of the guard handle, e.g. fp32,
+  // takes the every-ray pass through the generic dispatch)
+  const bool selective = a->nerf_guard && a->guard_threshold > 0.0f && a->N <= 64 && a->nerf_guard->dtype == NS_DTYPE_F16X3 &&
+                         a->nerf_guard->layout == 16;
   if (selective) {         // the kernel flags the rays itself; their last samples are re-evaluated after it
     rc = guard_check(a, a->N);
     if (rc != NS_OK) return rc;

@@ -421,6 +421,12 @@ def test_psnr_guard_replaces_sigma_of_the_last_sample(gpu_modules, dtype):
     assert torch.equal(shard[:, :3].view(torch.int32), every["rgb"].view(torch.int32)) and sel["rgb"].data_ptr() == shard.data_ptr()
     assert torch.equal(shard[:, 3].view(torch.int32), every["disp"].view(torch.int32))
     assert torch.equal(sel["weights"].view(torch.int32), every["weights"].view(torch.int32))
+    # a guard handle that is not a split-fp16 packing (here: exact fp32) takes the every-ray pass whatever the threshold says
+    g32 = m["fine"].packed("f32")
+    a32 = ops.render_rays_depthnet(dn, nf, rays=(o, d, view), n_samples=64, mode="uniform", std=0.1, one_kernel=True, guard=g32)
+    b32 = ops.render_rays_depthnet(dn, nf, rays=(o, d, view), n_samples=64, mode="uniform", std=0.1, one_kernel=False, guard=g32)
+    assert torch.equal(a32["rgb"].view(torch.int32), b32["rgb"].view(torch.int32))
+    assert float((a32["rgb"] - every["rgb"]).abs().max()) < 1e-3              # (the fp32 and the f16x3 sigma agree to fp32 rounding)
     with pytest.raises((NotImplementedError, ValueError)):                       # the guard pass is defined for uniform placement
         ops.render_rays_depthnet(dn, nf, camera=(H, W, K, c2w, 0, H), n_samples=8, mode="gaussian", std=0.1, guard=gw)
     with pytest.raises(ValueError):                                              # ... and for another packing of the SAME network
