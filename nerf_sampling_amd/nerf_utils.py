@@ -41,9 +41,11 @@ class _HostSink:
     concatenates the chunks on the host (another pass over ~0.8 GB per 800x800 frame).  Here the "concatenation" is the
     buffer itself and the copies of chunk i run UNDER THE NeRF-MLP KERNEL OF CHUNK i+1: put() only queues a copy, and
     release(after=ev) starts the queued ones once `ev` -- the event the one-call renderer records right before its MLP
-    kernel -- has been reached.  (Measured on MI355X: ROCm moves these copies with shader blit kernels; started right
-    after a chunk they run beside the next chunk's small kernels -- DepthNet, placement -- and stretch them tenfold,
-    while the MFMA-bound MLP kernel that follows runs alone.  Under the MLP kernel they are nearly free.)  The caller
+    kernel -- has been reached.  (Measured on MI355X: started right after a chunk the copies run beside the next chunk's
+    small kernels -- DepthNet, placement -- and stretch them tenfold, while the MFMA-bound MLP kernel that follows runs
+    alone; under the MLP kernel they are nearly free.  The copies go through the SDMA engines -- a kernel trace shows shader
+    blits only because the profiler switches the engines off -- at ~27 GB/s beside the MLP kernel, 57 GB/s alone:
+    profiles/r04f_api_path_copy_engines.log.)  The caller
     gets the same host tensors (same keys, shapes, dtypes, values).  Buffers come from torch's caching pinned allocator,
     fresh per frame, so tensors returned for one frame are never overwritten by the next (render_path keeps references
     across frames)."""
