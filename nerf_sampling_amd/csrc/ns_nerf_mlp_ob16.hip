@@ -541,7 +541,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
         //   1  every chunk on its wave: alpha, colours, the chunk's own transmittance scan; its factor P_c -> LDS
         //   2  carry entering the chunk = (the open ray's carry, if the ray began in an earlier group) x P of the ray's
         //      earlier chunks of this group, in order; weights; the chunk's five sums -> LDS
-        //   3  lane c of wave 0, for the chunk c that ends a ray or the group: totals in chunk order; a finished ray is written,
+        //   3  lane c of the last wave, for the chunk c that ends a ray or the group: totals in chunk order; a finished ray is written,
         //      the ray that stays open hands {carry, sums} to the next group
         const int m = a.m_chunks;
         const int64_t C0 = grp * T;                      // global index of the group's first chunk
@@ -597,7 +597,7 @@ nerf_mlp_ob16_kernel(Nerf16Args a) {
           }
         });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (wave == 0 && le < T) {
+        if (wave == NWAVES - 1 && le < T) {       // (the last wave: with five tiles wave 0 has had two chunks in phases 1 and 2, this one one)
           const int c = le;
           const int pos = static_cast<int>((C0 + c) % m);
           const bool ends = pos == m - 1;
