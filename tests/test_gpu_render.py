@@ -370,6 +370,35 @@ def test_fused_compositing_matches_operator_chain_16bit(gpu_modules, dtype, scen
 
 
 
+def test_one_kernel_renderers_on_a_handful_of_rays(gpu_modules):
+    """One, three and seven rays (a single, mostly empty workgroup; a several-chunk ray that is the launch's only run) through
+    the one-kernel renderer, its guards and the hierarchical renderer's in-epilogue compositing: the chain's bits."""
+    from nerf_sampling_amd import ops
+
+    m = gpu_modules("lego_synth")
+    dn, nf, gw, nc = m["depth"].packed("f16"), m["fine"].packed("bf16"), m["fine"].packed("f16x3"), m["coarse"].packed("bf16")
+    _, K = O.blender_intrinsics(8, 8)
+    o, d, view = ops.get_rays(8, 8, K, O.pose_spherical(10.0, -30.0, 4.0)[:3, :4])[:3]
+    for R in (1, 3, 7):
+        rays = (o[:R].contiguous(), d[:R].contiguous(), view[:R].contiguous())
+        for n in (64, 2, 192, 512):
+            for t in (0, 4, 5):
+                with ops.debug_switch(prod_tiles=t):
+                    a = ops.render_rays_depthnet(dn, nf, rays=rays, n_samples=n, mode="uniform", std=0.1, extras=True, one_kernel=True)
+                    b = ops.render_rays_depthnet(dn, nf, rays=rays, n_samples=n, mode="uniform", std=0.1, extras=True, one_kernel=False)
+                for k in ("rgb", "disp", "z", "weights", "pts"):
+                    assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), (R, n, t, k)
+        for thr in (0.0, 16.0, 1e6):
+            a = ops.render_rays_depthnet(dn, nf, rays=rays, n_samples=64, mode="uniform", std=0.1, one_kernel=True, guard=gw, guard_threshold=thr)
+            b = ops.render_rays_depthnet(dn, nf, rays=rays, n_samples=64, mode="uniform", std=0.1, one_kernel=False, guard=gw)
+            assert torch.equal(a["rgb"].view(torch.int32), b["rgb"].view(torch.int32)) or thr == 16.0, (R, thr)
+        h1 = ops.render_rays_hierarchical(nc, nf, rays=rays, n_coarse=64, n_importance=128, extras=True)
+        with ops.debug_switch(hier_chain=1):
+            h0 = ops.render_rays_hierarchical(nc, nf, rays=rays, n_coarse=64, n_importance=128, extras=True)
+        for k in ("rgb", "disp", "z", "weights", "raw"):
+            assert torch.equal(h1[k].view(torch.int32), h0[k].view(torch.int32)), (R, k)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_psnr_guard_replaces_sigma_of_the_last_sample(gpu_modules, dtype):
     """ns_render_args::nerf_guard on both one-call renderers: the last sample of every ray -- composited with dist = 1e10, so
