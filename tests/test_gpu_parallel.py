@@ -30,9 +30,15 @@ def _worker(rank, world, port, out_dir):
         _, K = synthetic.blender_intrinsics(H, W)
         fr = FrameRenderer(H, W, hip_row_renderer(m["depth"].packed("f32"), m["fine"].packed("f32"), H, W, K, 16, "uniform",
                                                   0.1, device="cuda:0"), "cuda:0")
+        # the headline path: bf16 field through the ONE-KERNEL renderer with the selective PSNR guard (its fix-up kernels write the
+        # flagged pixels into the gather shard through the shard's strides)
+        fg = FrameRenderer(H, W, hip_row_renderer(m["depth"].packed("f16x3"), m["fine"].packed("bf16"), H, W, K, 16, "uniform", 0.1,
+                                                  device="cuda:0", guard=m["fine"].packed("f16x3"), guard_threshold=4.0), "cuda:0")
         for k, theta in enumerate((15.0, 200.0)):
             rgb, disp = fr.render(synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4])
-            np.savez(os.path.join(out_dir, f"r{rank}_f{k}.npz"), rgb=rgb.cpu().numpy(), disp=disp.cpu().numpy())
+            rgb_g, disp_g = fg.render(synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4])
+            np.savez(os.path.join(out_dir, f"r{rank}_f{k}.npz"), rgb=rgb.cpu().numpy(), disp=disp.cpu().numpy(),
+                     rgb_g=rgb_g.cpu().numpy(), disp_g=disp_g.cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -51,10 +57,15 @@ def test_two_ranks_assemble_the_single_process_frame(tmp_path, gpu_modules):
         full = ops.render_rays_depthnet(m["depth"].packed("f32"), m["fine"].packed("f32"),
                                         camera=(H, W, K, synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4], 0, H),
                                         n_samples=16, mode="uniform", std=0.1)
+        guarded = ops.render_rays_depthnet(m["depth"].packed("f16x3"), m["fine"].packed("bf16"),
+                                           camera=(H, W, K, synthetic.pose_spherical(theta, -30.0, 4.0)[:3, :4], 0, H), n_samples=16,
+                                           mode="uniform", std=0.1, guard=m["fine"].packed("f16x3"), guard_threshold=4.0, one_kernel=True)
         for r in range(2):
             got = np.load(os.path.join(str(tmp_path), f"r{r}_f{k}.npz"))
             np.testing.assert_array_equal(got["rgb"].reshape(-1, 3), full["rgb"].cpu().numpy())   # bit exact
             np.testing.assert_array_equal(got["disp"].reshape(-1), full["disp"].cpu().numpy())
+            np.testing.assert_array_equal(got["rgb_g"].reshape(-1, 3), guarded["rgb"].cpu().numpy())
+            np.testing.assert_array_equal(got["disp_g"].reshape(-1), guarded["disp"].cpu().numpy())
 
 
 @pytest.mark.parametrize("world", [2, 4])
