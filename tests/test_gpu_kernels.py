@@ -166,6 +166,31 @@ def test_raw2outputs(ops, golden, N, wb):
     close(disp, g[p + "disp"], 2e-5, 1e-6)
 
 
+def test_compositing_on_the_transcendental_unit_keeps_its_absolute_error_bound(ops):
+    """ns_composite_ray.h evaluates exp on v_exp_f32 (the argument times log2 e, rounded once) and 1 / x on v_rcp_f32.  What
+    compositing uses are 1 - exp(-s) and 1 / (1 + exp(-x)): their ABSOLUTE error stays at the rounding of the fp32 result for
+    every argument -- checked here against float64 over the whole range the kernels can see, far beyond what
+    the golden fixtures contain: sigma * dist from 1e-6 to 1e4, colour logits from -60 to 60."""
+    R = 4096
+    gen = torch.Generator().manual_seed(5)
+    # two samples per ray: sample 0 opaque (alpha = 1 exactly), so rgb = sigmoid(raw[0, :3]); sample 0's alpha probes 1 - exp(-s)
+    x = (torch.rand(R, 3, generator=gen) * 2 - 1) * 60.0
+    s = 10.0 ** (torch.rand(R, generator=gen) * 10 - 6)                       # sigma * dist (dist = 1: z = [2, 3], unit d)
+    raw = torch.zeros(R, 2, 4)
+    raw[:, 0, :3] = x
+    raw[:, 0, 3] = 1e6
+    z = torch.tensor([[2.0, 3.0]]).expand(R, 2).contiguous()
+    d = torch.tensor([[0.0, 0.0, 1.0]]).expand(R, 3).contiguous()
+    rgb = ops.raw2outputs(raw.cuda(), z.cuda(), d.cuda(), None, False)[0].cpu().double()
+    err_c = (rgb - torch.sigmoid(x.double())).abs().max().item()
+    raw2 = torch.zeros(R, 2, 4)
+    raw2[:, 0, 3] = s
+    alphas = ops.raw2outputs(raw2.cuda(), z.cuda(), d.cuda(), None, False)[4].cpu().double()
+    err_a = (alphas[:, 0] - (1.0 - torch.exp(-s.double()))).abs().max().item()
+    print(f"compositing on the transcendental unit: max |sigmoid err| {err_c:.2e}, max |alpha err| {err_a:.2e}")
+    assert err_c < 1.5e-7 and err_a < 1.5e-7, (err_c, err_a)
+
+
 def test_raw2outputs_noise_and_trainer_signature(ops, golden):
     from nerf_sampling_amd.trainers import DepthNetTrainer
 
