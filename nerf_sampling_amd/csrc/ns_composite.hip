@@ -6,6 +6,16 @@
 
 namespace {
 
+// compile-time loops over powers of two: F(J), F(J / 2), ..., F(1)  and  F(K), F(2 K), ..., F(KMAX)
+template <int J, class F>
+__device__ __forceinline__ void static_for_pow2_down(F&& f) {
+  if constexpr (J >= 1) { f(std::integral_constant<int, J>{}); static_for_pow2_down<J / 2>(f); }
+}
+template <int K, int KMAX, class F>
+__device__ __forceinline__ void static_for_pow2_up(F&& f) {
+  if constexpr (K <= KMAX) { f(std::integral_constant<int, K>{}); static_for_pow2_up<2 * K, KMAX>(f); }
+}
+
 __device__ __forceinline__ float linspace01(int steps, int i) {
   if (steps <= 1) return 0.0f;
   const float step = 1.0f / static_cast<float>(steps - 1);
@@ -270,22 +280,37 @@ importance_z_wave_kernel(const float* __restrict__ z, const float* __restrict__ 
     if (lane < Nb - 1) cdf_s[lane + 1] = static_cast<float>(run);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // The 64 NR slots as a BITONIC sequence: the coarse depths ascending in slots [0, Nc), NaN (sorts last) in the middle, the new
+    // samples in REVERSE order at the end (sample s in slot 64 NR - 1 - s).  With deterministic draws (u = linspace) the inverse
+    // CDF is non-decreasing in u, so the sequence rises, stays at its maximum and falls: ONE merge stage of the network (log2(64 NR)
+    // compare-exchange steps) sorts it; the full network (36 steps at NR = 4) runs only when the wave finds either run out of order
+    // -- random draws, or a rounding inversion at a bin boundary -- so the result is the sorted row either way.
+    constexpr int P = 64 * NR;
     float e[NR];
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
       const int i = q * 64 + lane;
       if (i < Nc) e[q] = zk;                      // only q == 0: Nc <= 64
-      else if (i < tot) {
-        const int sidx = i - Nc;
+      else if (i >= P - Nf) {
+        const int sidx = P - 1 - i;
         const float uu = u ? u[r * Nf + sidx] : linspace01(Nf, sidx);
         e[q] = invert_cdf(cdf_s, bins_s, Nb, uu);
       } else e[q] = __builtin_nanf("");
     }
+    bool in_order = true;                         // slot i against slot i - 1, inside the two runs
 #pragma unroll
-    for (int k = 2; k <= 64 * NR; k <<= 1) {
-#pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        if (j >= 64) {
+    for (int q = 0; q < NR; ++q) {
+      const int i = q * 64 + lane;
+      float prev = __shfl_up(e[q], 1, 64);
+      if (q > 0) { const float carry = __shfl(e[q - 1], 63, 64); if (lane == 0) prev = carry; }
+      if (i >= 1 && i < Nc) in_order = in_order && (e[q] >= prev);
+      if (i > P - Nf) in_order = in_order && (e[q] <= prev);
+    }
+    auto stage = [&](auto k_) {                   // one stage of the bitonic network: blocks of k slots, alternating direction
+      constexpr int k = decltype(k_)::value;
+      static_for_pow2_down<k / 2>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j >= 64) {
 #pragma unroll
           for (int q = 0; q < NR; ++q) {
             const int pq = q ^ (j >> 6);
@@ -309,7 +334,12 @@ importance_z_wave_kernel(const float* __restrict__ z, const float* __restrict__ 
             e[q] = take_min ? (other_less ? other : mine) : (mine_less ? other : mine);
           }
         }
-      }
+      });
+    };
+    if (__builtin_amdgcn_ballot_w64(in_order) == __builtin_amdgcn_ballot_w64(true)) {
+      stage(std::integral_constant<int, P>{});
+    } else {
+      static_for_pow2_up<2, P>([&](auto k_) { stage(k_); });
     }
 #pragma unroll
     for (int q = 0; q < NR; ++q) {

@@ -269,6 +269,16 @@ def test_importance_z_shapes(ops, Nc, Nf, random_u):
     assert (mine[:, 1:] >= mine[:, :-1]).all()
     err = (mine - ref).abs().numpy()
     assert np.mean(err > 2e-5) < 5e-3 and np.median(err) < 1e-6
+    if not random_u:
+        # the wave kernel sorts deterministic draws with ONE merge stage when the coarse depths ascend and the new samples do too;
+        # rows that do not (here: descending coarse depths) must take the full network and still come out as torch.sort gives them
+        zd = zc.flip(-1).contiguous()
+        z_mid = 0.5 * (zd[..., 1:] + zd[..., :-1])
+        ref = torch.sort(torch.cat([zd, O.sample_pdf(z_mid, w[..., 1:-1], Nf, det=True)], -1), -1).values
+        mine = ops.importance_z(zd.cuda(), w.cuda(), Nf, None).cpu()
+        assert (mine[:, 1:] >= mine[:, :-1]).all()
+        err = (mine - ref).abs().numpy()
+        assert np.mean(err > 2e-5) < 5e-3 and np.median(err) < 1e-6
 
 
 def test_argmax_gather(ops):
