@@ -41,3 +41,38 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
     with pytest.raises(_lib.NativeLibraryError):
         _lib.load()
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """The three argument structs are mirrored by hand in _lib.py: a C program that includes the public header prints sizeof and
+    the offset of every field (gcc; the header is plain C), and the ctypes classes must agree field by field -- a field added to
+    the header and not to the mirror (or the other way round) fails here, on a CPU-only box, instead of corrupting a launch."""
+    import ctypes
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    pairs = {"ns_render_args": _lib.RenderArgs, "ns_hier_args": _lib.HierArgs, "ns_gemm_problem": _lib.GemmProblem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nerf_sampling_hip.h"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    # every field the header declares is mirrored: the struct bodies name as many members as the ctypes classes
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nerf_sampling_hip.h")).read(), flags=re.S)
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", text, flags=re.S).group(1)
+        n_members = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
